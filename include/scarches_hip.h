@@ -1,0 +1,116 @@
+/* scarches_hip.h - C ABI of the MI355X-native conditional-VAE train/map step (libscarches_hip.so).
+ *
+ * The reference (theislab/scarches v0.6.1) is pure Python on PyTorch and has no FFI layer; its narrowest seam is
+ * `nn.Module.forward(...) -> (recon, kl, mmd)` + `loss.backward()` + `optimizer.step()`
+ * (scarches/trainers/trvae/unsupervised.py:62-64, trainers/trvae/trainer.py:272-280).  Each entry point below
+ * replaces the ATen op sequence the reference runs for one piece of that seam; the citation names the reference
+ * lines whose result it reproduces.  All pointers are DEVICE pointers unless stated; all matrices are row-major
+ * fp32; `stream` is a hipStream_t passed as void* (NULL = default stream).  Every function only enqueues work
+ * (no allocation, no synchronisation) and returns 0 on success, a negative value for an unsupported shape /
+ * argument, or a positive hipError_t.
+ *
+ * Reference-side binding: see INTEGRATION.md (ctypes stubs a maintainer would add next to the reference modules).
+ */
+#ifndef SCARCHES_HIP_H
+#define SCARCHES_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Library / device sanity: returns the ABI version; fills name[0..len) with the HIP device name (host buffer). */
+int sca_abi_version(void);
+int sca_device_name(char* name, int len);
+
+/* ---- CSR minibatch loader ------------------------------------------------------------------------------------
+ * Replaces AnnotatedDataset.__getitem__ + custom_collate (scarches/dataset/trvae/anndata.py:74-92,
+ * trainers/trvae/_utils.py:208-240) and the log1p of trVAE.forward (models/trvae/trvae.py:117):
+ * xout[b,:] = (apply_log1p ? log(1+x) : x) of CSR row row_ids[b] (row_ids NULL: rows 0..B-1),
+ * sizefactor[b] = sum of the raw row (dataset/trvae/anndata.py:44).  CSR must be canonical (unique, any order). */
+int sca_csr_gather_rows(const int64_t* indptr, const int32_t* indices, const float* data, const int64_t* row_ids,
+                        int B, int G, int apply_log1p, float* xout, int ldx, float* sizefactor, void* stream);
+int sca_dense_gather_rows(const float* X, int ldX, const int64_t* row_ids, int B, int G, int apply_log1p,
+                          float* xout, int ldx, float* sizefactor, void* stream);
+
+/* ---- fp32 MFMA GEMM ------------------------------------------------------------------------------------------
+ * Replaces the nn.Linear / one-hot GEMMs of CondLayers, Encoder, Decoder (models/trvae/modules.py:21-27,77,86-87,
+ * 159,173-181) and their autograd backward.  C[m][n] = sum_k A(m,k) B(k,n);
+ *   amode 0: A(m,k)=A[m*lda+k]   amode 1: A(m,k)=A[k*lda+m]
+ *   bmode 0: B(k,n)=B[n*ldb+k]   bmode 1: B(k,n)=B[k*ldb+n]
+ * splitk > 1 writes `splitk` partial slabs C + s*slab_stride (consumers sum them); bias[n] (optional) is added
+ * only when splitk == 1. */
+int sca_gemm_splitk_heuristic(int M, int N, int K);
+int sca_gemm_f32(int amode, int bmode, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
+                 int N, int K, int splitk, long long slab_stride, const float* bias, void* stream);
+int sca_splitk_reduce(const float* slabs, int S, long long slab_stride, float* dst, long long n, void* stream);
+
+/* ---- layer epilogues -----------------------------------------------------------------------------------------
+ * sca_layer_fwd: sum of S GEMM slabs + bias + condition column Wc[:,cond[b]] (or dense condition vector
+ * cvec[b,:E] . Wc[h,:E], scPoli embeddings: models/scpoli/scpoli.py:137-150) -> LayerNorm(no affine, eps 1e-5)
+ * (norm=1) -> ReLU -> Dropout(p) (models/trvae/modules.py:78-84).  mask: optional injected keep-mask [B][H] (parity
+ * tests); otherwise Philox(seed + *step, rng_stream).  Writes ynorm (pre-ReLU, needed by backward), rstd, h.
+ * sca_layer_bwd: gradient through Dropout, ReLU, LayerNorm: da = d loss / d (Linear output).
+ * sca_cond_colsum: dWc[h][c] = sum_{b: cond[b]=c} da[b][h]; db[h] = sum_b da[b][h] (autograd of the one-hot GEMM and
+ * the bias broadcast).  segT: scratch of max(C,1)*H floats. */
+int sca_layer_fwd(const float* slabs, int S, long long slab_stride, int B, int H, const float* bias, const float* Wc,
+                  int C, const int32_t* cond, const float* cvec, int E, int norm, int relu, float p,
+                  const uint8_t* mask, uint64_t seed, uint32_t rng_stream, const uint32_t* step, float* ynorm,
+                  float* rstd, float* h, void* stream);
+int sca_layer_bwd(const float* dh, int S, long long slab_stride, const float* extra, int B, int H, const float* ynorm,
+                  const float* rstd, int norm, int relu, float p, const uint8_t* mask, uint64_t seed,
+                  uint32_t rng_stream, const uint32_t* step, float* da, void* stream);
+int sca_cond_colsum(const float* da, int B, int H, const int32_t* cond, int C, float* segT, float* dWc, float* db,
+                    void* stream);
+
+/* ---- latent block --------------------------------------------------------------------------------------------
+ * heads = [mean | log_var] GEMM slabs.  z = mu + eps*sqrt(exp(logvar)+1e-4) (models/base/_base.py:391-407),
+ * kl_row[b] = sum_z KL(N(mu,sigma)||N(0,1)) (models/trvae/trvae.py:143-147).  eps NULL: Philox noise.
+ * sample=0 gives z = mu (get_latent(mean=True), models/base/_base.py:409-432).
+ * sca_latent_bwd: d/d[mean|log_var] of  (upstream dz + dz2) + hyper[0]/B * KL. */
+int sca_latent_fwd(const float* heads, int S, long long slab_stride, const float* bias, int B, int Z, const float* eps,
+                   uint64_t seed, uint32_t rng_stream, const uint32_t* step, int sample, float* mu_lv, float* eps_out,
+                   float* z, float* kl_row, void* stream);
+int sca_latent_bwd(const float* dz, int S, long long slab_stride, const float* dz2, int S2, long long slab_stride2,
+                   const float* mu_lv, const float* eps, const float* hyper, int B, int Z, float* dheads, void* stream);
+
+/* ---- reconstruction losses -----------------------------------------------------------------------------------
+ * sca_theta_prep: tab_theta[c][g] = exp(theta[g][c]), tab_lte[c][g] = log(tab_theta + 1e-8) (trvae.py:139-140).
+ * sca_recon_rows: softmax over genes, x size factor, NB (zinb=0, models/trvae/losses.py:63-102) or ZINB (zinb=1,
+ * losses.py:109-163) log-likelihood with counts read straight from CSR, and - when compute_grad - the gradient of
+ * recon = -sum/B written IN PLACE over logits (and pi), theta gradients accumulated (unscaled sum_b theta*dll/dtheta)
+ * into dthetaT[C][G] and the output-bias gradients into dbias[G] (both must be zeroed by the caller).
+ * sca_mse_rows: ReLU head + sum of squares (trvae.py:125-127).
+ * sca_transpose_scale: dst[cols][rows] = scale * src[rows][cols] (dthetaT -> theta.grad layout [G][C]). */
+int sca_theta_prep(const float* theta, int G, int C, float* tab_theta, float* tab_lte, void* stream);
+int sca_recon_rows(int zinb, float* logits, int ldl, float* pi, const int64_t* indptr, const int32_t* indices,
+                   const float* data, const int64_t* row_ids, const float* sizefactor, const int32_t* cond,
+                   const float* tab_theta, const float* tab_lte, int B, int G, int C, int rows_per_block, float* row_ll,
+                   float* dthetaT, float* dbias, float* dbias_pi, int compute_grad, void* stream);
+int sca_mse_rows(float* lin, int ldl, const float* x, int ldx, int B, int G, int rows_per_block, float* row_loss,
+                 float* dbias, int compute_grad, void* stream);
+int sca_transpose_scale(const float* src, int rows, int cols, float scale, float* dst, void* stream);
+
+/* ---- MMD -----------------------------------------------------------------------------------------------------
+ * Multi-scale RBF MMD between condition blocks (models/trvae/losses.py:166-270, _utils.py:18-24), forward value as
+ * double partial sums (sum them) and gradient w.r.t. feat as sca_mmd_num_slabs(B,D) slabs [B][D] (sum them).
+ * boundary < 0: all pairs.  Wt: scratch [C][C]; counts: optional [C]. */
+int sca_mmd_num_slabs(int B, int D);
+int sca_mmd_num_partials(int B, int D);
+int sca_mmd_fwd_bwd(const float* feat, int ld, const int32_t* cond, int B, int D, int C, int boundary, float beta,
+                    float* Wt, int32_t* counts, double* loss_part, float* grad_slabs, long long slab_stride,
+                    void* stream);
+
+/* ---- optimiser / bookkeeping ---------------------------------------------------------------------------------
+ * hyper (device, float[8]): [0] alpha_kl  [1] lr  [2] 1-beta1^t  [3] sqrt(1-beta2^t)  [4] adam eps  [5] clip value.
+ * sca_adam_step: torch.optim.Adam semantics (trainers/trvae/trainer.py:221-223, clip: :277-278) on a flat range.
+ * sca_finalize_losses: losses[0..3] = recon (= recon_sign * sum(row_recon)/B), kl, mmd, recon + alpha*kl + mmd
+ * (trainers/trvae/unsupervised.py:62-70); accum[0..3] += those, accum[4] += 1 (per-epoch log means without syncs). */
+int sca_adam_step(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1,
+                  float beta2, float weight_decay, void* stream);
+int sca_finalize_losses(const float* row_recon, float recon_sign, const float* row_kl, int B, const double* mmd_part,
+                        int n_part, const float* hyper, float* losses, double* accum, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

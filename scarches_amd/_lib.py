@@ -1,0 +1,93 @@
+"""ctypes binding of libscarches_hip.so (C ABI declared in include/scarches_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails, the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libscarches_hip.so")
+
+P = C.c_void_p
+I = C.c_int
+LL = C.c_longlong
+F = C.c_float
+U64 = C.c_uint64
+U32 = C.c_uint32
+
+# name -> argtypes (restype is always int); mirrors include/scarches_hip.h one to one
+SIGNATURES = {
+    "sca_abi_version": [],
+    "sca_device_name": [C.c_char_p, I],
+    "sca_csr_gather_rows": [P, P, P, P, I, I, I, P, I, P, P],
+    "sca_dense_gather_rows": [P, I, P, I, I, I, P, I, P, P],
+    "sca_gemm_splitk_heuristic": [I, I, I],
+    "sca_gemm_f32": [I, I, P, I, P, I, P, I, I, I, I, I, LL, P, P],
+    "sca_splitk_reduce": [P, I, LL, P, LL, P],
+    "sca_layer_fwd": [P, I, LL, I, I, P, P, I, P, P, I, I, I, F, P, U64, U32, P, P, P, P, P],
+    "sca_layer_bwd": [P, I, LL, P, I, I, P, P, I, I, F, P, U64, U32, P, P, P],
+    "sca_cond_colsum": [P, I, I, P, I, P, P, P, P],
+    "sca_latent_fwd": [P, I, LL, P, I, I, P, U64, U32, P, I, P, P, P, P, P],
+    "sca_latent_bwd": [P, I, LL, P, I, LL, P, P, P, I, I, P, P],
+    "sca_theta_prep": [P, I, I, P, P, P],
+    "sca_recon_rows": [I, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, I, P],
+    "sca_mse_rows": [P, I, P, I, I, I, I, P, P, I, P],
+    "sca_transpose_scale": [P, I, I, F, P, P],
+    "sca_mmd_num_slabs": [I, I],
+    "sca_mmd_num_partials": [I, I],
+    "sca_mmd_fwd_bwd": [P, I, P, I, I, I, I, F, P, P, P, P, LL, P],
+    "sca_adam_step": [P, P, P, P, LL, P, F, F, F, P],
+    "sca_finalize_losses": [P, F, P, I, P, I, P, P, P, P],
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP sources in-tree for gfx950 (hipcc cross-compiles; no GPU needed)."""
+    res = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
+    if verbose:
+        print(res.stdout[-2000:], res.stderr[-2000:])
+    if res.returncode != 0 or not os.path.exists(LIB_PATH):
+        raise HipLibraryError("building libscarches_hip.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+    return LIB_PATH
+
+
+def load():
+    """Load the shared library and declare every symbol of the header.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found - build it with `make -C scarches_amd/csrc` (or __graft_entry__.build()); "
+            "scarches_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"symbol {name} missing from {LIB_PATH}") from e
+        fn.argtypes = argtypes
+        fn.restype = I
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise HipLibraryError(f"{what} failed with code {rc}"
+                              + (" (unsupported shape/argument)" if rc < 0 else " (hipError_t)"))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

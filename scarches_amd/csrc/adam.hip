@@ -1,0 +1,83 @@
+// Optimiser step and loss bookkeeping (gfx950).
+//
+// Adam exactly as torch.optim.Adam(lr, betas=(0.9, 0.999), eps, weight_decay, amsgrad=False) applies it - the
+// configuration of scarches/trainers/trvae/trainer.py:221-223 (eps = 0.01, weight_decay = 0.04, L2 folded into the
+// gradient, NOT AdamW) - fused over a flat parameter range, with the optional clip_grad_value_ of trainer.py:277-278.
+// Per-step scalars (lr, bias corrections, KL weight) are read from a small device buffer so that a captured HIP graph
+// of the whole train step can be replayed without re-recording:
+//   hyper[0] = alpha_kl   hyper[1] = lr   hyper[2] = 1 - beta1^t   hyper[3] = sqrt(1 - beta2^t)
+//   hyper[4] = adam eps   hyper[5] = clip value (<= 0: off)
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long long n,
+                                                   const float* __restrict__ hyper, float beta1, float beta2,
+                                                   float weight_decay) {
+    const float lr = hyper[1], bc1 = hyper[2], bc2s = hyper[3], eps = hyper[4], clip = hyper[5];
+    const float step_size = lr / bc1;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float gi = g[i];
+        if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+        const float pi = p[i];
+        gi = fmaf(weight_decay, pi, gi);
+        float mi = m[i], vi = v[i];
+        mi = mi + (1.0f - beta1) * (gi - mi);           // torch: exp_avg.lerp_(grad, 1 - beta1)
+        vi = beta2 * vi + (1.0f - beta2) * gi * gi;
+        const float denom = sqrtf(vi) / bc2s + eps;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
+// losses[0..3] = recon, kl, mmd, total (= recon + alpha*kl + mmd);  accum[0..3] += the same; accum[4] += 1.
+__global__ __launch_bounds__(256) void finalize_losses_kernel(const float* __restrict__ row_recon, float recon_sign,
+                                                              const float* __restrict__ row_kl, int B,
+                                                              const double* __restrict__ mmd_part, int n_part,
+                                                              const float* __restrict__ hyper,
+                                                              float* __restrict__ losses, double* __restrict__ accum) {
+    __shared__ double red[16];
+    double r = 0.0, k = 0.0, mm = 0.0;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        r += (double)row_recon[i];
+        if (row_kl) k += (double)row_kl[i];
+    }
+    for (int i = threadIdx.x; i < n_part; i += 256) mm += mmd_part[i];
+    r = block_sum_d(r, red);
+    k = block_sum_d(k, red);
+    mm = block_sum_d(mm, red);
+    if (threadIdx.x == 0) {
+        const double recon = recon_sign * r / (double)B, kl = k / (double)B;
+        const double tot = recon + (double)hyper[0] * kl + mm;
+        losses[0] = (float)recon; losses[1] = (float)kl; losses[2] = (float)mm; losses[3] = (float)tot;
+        if (accum) {
+            // the reference logs float32 `.item()` values per iteration and averages them per epoch
+            accum[0] += (double)(float)recon; accum[1] += (double)(float)kl; accum[2] += (double)(float)mm;
+            accum[3] += (double)(float)tot; accum[4] += 1.0;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int sca_adam_step(float* p, const float* g, float* m, float* v, long long n, const float* hyper,
+                             float beta1, float beta2, float weight_decay, void* stream) {
+    if (n <= 0) return 0;
+    long long nb = (n + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, hyper, beta1,
+                       beta2, weight_decay);
+    SCA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sca_finalize_losses(const float* row_recon, float recon_sign, const float* row_kl, int B,
+                                   const double* mmd_part, int n_part, const float* hyper, float* losses,
+                                   double* accum, void* stream) {
+    hipLaunchKernelGGL(finalize_losses_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_recon, recon_sign,
+                       row_kl, B, mmd_part, n_part, hyper, losses, accum);
+    SCA_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,323 @@
+// Reconstruction losses of the conditional VAE, forward + backward in one pass over the decoder output
+// (gfx950).  Restates, per cell row b with condition c_b and size factor s_b:
+//     gamma = softmax(logits_b)                                  scarches/models/trvae/modules.py:181
+//     mu    = gamma * s_b ; theta = exp(theta[:, c_b])           scarches/models/trvae/trvae.py:136-140
+//     NB    log-lik                                              scarches/models/trvae/losses.py:93-100
+//     ZINB  log-lik (softplus forms, x<eps / x>eps cases)        scarches/models/trvae/losses.py:144-162
+//     recon = -sum_g ll / B                                      scarches/models/trvae/trvae.py:141
+// and the MSE head (ReLU output, sum of squares)                 trvae.py:125-127, losses.py:27-42.
+//
+// Design: a workgroup holds one whole row of logits in registers, so softmax statistics, the likelihood,
+// the softmax backward (needs sum_k mu_k dll/dmu_k) and the in-place dlogits store cost ONE read and ONE
+// write of the B x G matrix.  Counts are read straight from CSR: at x = 0 every lgamma/digamma term cancels
+// exactly, so the dense sweep is 1 exp + 1 log + 1 rcp per element and the lgamma/digamma work (fp64, for
+// cancellation-free lgamma(x+theta)-lgamma(theta)) runs only on the row's nnz, one lane per stored count.
+// theta gradients are kept in registers/LDS across the rows a workgroup owns and flushed with coalesced
+// atomics once per condition run (minibatches arrive condition-sorted), the output-bias gradient likewise.
+#include "common.h"
+
+namespace {
+
+constexpr float NB_EPS = 1e-8f;
+
+__device__ __forceinline__ float softplus_t(float x) {   // torch.nn.functional.softplus (beta 1, threshold 20)
+    return x > 20.f ? x : log1pf(expf(x));
+}
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// tab_theta[c][g] = exp(theta[g][c]),  tab_lte[c][g] = log(exp(theta[g][c]) + eps)
+__global__ __launch_bounds__(256) void theta_prep_kernel(const float* __restrict__ theta, int G, int C,
+                                                         float* __restrict__ tab_theta, float* __restrict__ tab_lte) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= G * C) return;
+    const int c = i / G, g = i - c * G;
+    const float th = expf(theta[(long long)g * C + c]);
+    tab_theta[i] = th;
+    tab_lte[i] = logf(th + NB_EPS);
+}
+
+// dtheta[g][c] = scale * dthetaT[c][g]
+__global__ __launch_bounds__(256) void transpose_scale_kernel(const float* __restrict__ src, int R, int Ccols,
+                                                              float scale, float* __restrict__ dst) {
+    // src [R][Ccols] -> dst [Ccols][R]
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * Ccols) return;
+    const int cc = i / R, r = i - cc * R;       // dst index = cc*R + r
+    dst[i] = scale * src[(long long)r * Ccols + cc];
+}
+
+struct ReconArgs {
+    float* logits; int ldl;         // [B][G]: in = decoder linear output (bias included); out = d loss / d logits
+    float* pi;                      // ZINB only: in = dropout logits, out = d loss / d pi
+    const int64_t* indptr; const int32_t* indices; const float* data; const int64_t* row_ids;
+    const float* sizefactor; const int32_t* cond;
+    const float* tab_theta; const float* tab_lte;   // [C][G]
+    int B, G, C, rows_per_block;
+    float* row_ll;                  // [B] sum_g ll
+    float* dthetaT;                 // [C][G] accumulates sum_b theta * dll/dtheta (unscaled), pre-zeroed
+    float* dbias; float* dbias_pi;  // [G] accumulate column sums of dlogits / dpi, pre-zeroed (may be null)
+    int compute_grad;
+};
+
+template <int T, int EPT, bool ZINB>
+__global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* tx = lds;              // [G] per-row extras of t = mu dll/dmu at nnz (cleared by the owner when read)
+    float* dx = lds + a.G;        // [G] theta-gradient extras, accumulated over the rows of a condition run
+    float* px = lds + 2 * a.G;    // [G] ZINB: dpi extras (cleared when read)
+    __shared__ float red[16];
+    const int G = a.G, t = threadIdx.x;
+    const int nlds = (ZINB ? 3 : 2) * G;
+    for (int i = t; i < nlds; i += T) lds[i] = 0.f;
+
+    float acc_th[EPT], acc_b[EPT], acc_p[EPT];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) acc_th[j] = acc_b[j] = acc_p[j] = 0.f;
+
+    const int b0 = blockIdx.x * a.rows_per_block, b1 = min(a.B, b0 + a.rows_per_block);
+    const float invB = 1.0f / (float)a.B;
+    for (int b = b0; b < b1; ++b) {
+        const int c = a.cond ? a.cond[b] : 0;
+        const float s = a.sizefactor[b];
+        float* lrow = a.logits + (long long)b * a.ldl;
+        float* prow = ZINB ? a.pi + (long long)b * a.ldl : nullptr;
+        const float* tth = a.tab_theta + (long long)c * G;
+        const float* tlt = a.tab_lte + (long long)c * G;
+
+        float lg[EPT];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int g = t + T * j;
+            lg[j] = g < G ? lrow[g] : -INFINITY;
+            mx = fmaxf(mx, lg[j]);
+        }
+        mx = block_max(mx, red);
+        float se = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            lg[j] = (t + T * j < G) ? expf(lg[j] - mx) : 0.f;      // lg now holds exp(l - max)
+            se += lg[j];
+        }
+        se = block_sum(se, red);
+        const float inv = 1.0f / se;
+
+        // ---- sparse phase: one lane per stored count of this row
+        float ll = 0.f, Tsum = 0.f;
+        const int64_t r = a.row_ids ? a.row_ids[b] : (int64_t)b;
+        const int64_t ks = a.indptr[r], ke = a.indptr[r + 1];
+        for (int64_t k = ks + t; k < ke; k += T) {
+            const float x = a.data[k];
+            if (!(x > NB_EPS)) continue;
+            const int g = a.indices[k];
+            const float th = tth[g];
+            const float mu = expf(lrow[g] - mx) * inv * s;
+            const float den = th + mu + NB_EPS;
+            const float L = logf(den), rr = 1.0f / den;
+            const double xd = (double)x, thd = (double)th;
+            const double lgam = lgamma(xd + thd) - lgamma(thd) - lgamma(xd + 1.0);
+            const double dig = digamma_pos(xd + thd) - digamma_pos(thd);
+            float ex_ll = x * (logf(mu + NB_EPS) - L) + (float)lgam;
+            float ex_t = mu * (x / (mu + NB_EPS) - x * rr);
+            float ex_th = th * (-x * rr + (float)dig);
+            if (ZINB) {
+                // replace the zero-case (evaluated for every gene in the dense sweep) by the non-zero case
+                const float pv = prow[g];
+                const float base = th * (tlt[g] - L);
+                const float ptl = -pv + base;
+                const float sg = sigmoid_f(ptl);
+                const float dbase_dth = tlt[g] - L + th / (th + NB_EPS) - th * rr;
+                ex_ll += ptl - softplus_t(ptl);                      // (-sp + ptl + ..) - (softplus(ptl) - sp)
+                ex_t += (1.0f - sg) * (-mu * th * rr);
+                ex_th += th * (1.0f - sg) * dbase_dth;
+                px[g] = -1.0f + sg;                                   // (sig(-pi) - 1) - (sig(-pi) - sg)
+            }
+            ll += ex_ll;
+            tx[g] = ex_t;                 // joins t_g (and the row total T) in the dense sweep
+            dx[g] += ex_th;
+        }
+        __syncthreads();
+
+        // ---- dense sweep (x = 0 terms for every gene)
+        float tj[EPT], pj[EPT];
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int g = t + T * j;
+            tj[j] = 0.f; pj[j] = 0.f;
+            if (g < G) {
+                const float th = tth[g], lte = tlt[g];
+                const float gam = lg[j] * inv;
+                const float mu = gam * s;
+                const float den = th + mu + NB_EPS;
+                const float L = logf(den), rr = 1.0f / den;
+                const float base = th * (lte - L);
+                const float dbase_dth = lte - L + th / (th + NB_EPS) - th * rr;
+                float tv, dth;
+                if (ZINB) {
+                    const float pv = prow[g];
+                    const float ptl = -pv + base;
+                    const float sg = sigmoid_f(ptl);
+                    ll += softplus_t(ptl) - softplus_t(-pv);
+                    tv = sg * (-mu * th * rr);
+                    dth = th * sg * dbase_dth;
+                    pj[j] = (sigmoid_f(-pv) - sg) + px[g];
+                    px[g] = 0.f;
+                } else {
+                    ll += base;
+                    tv = -mu * th * rr;
+                    dth = th * dbase_dth;
+                }
+                tv += tx[g];
+                tx[g] = 0.f;
+                tj[j] = tv;
+                Tsum += tv;
+                acc_th[j] += dth;
+                lg[j] = gam;                                          // lg now holds gamma
+            }
+        }
+        ll = block_sum(ll, red);
+        Tsum = block_sum(Tsum, red);
+        if (t == 0) a.row_ll[b] = ll;
+
+        if (a.compute_grad) {
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                const int g = t + T * j;
+                if (g < G) {
+                    const float dl = (lg[j] * Tsum - tj[j]) * invB;
+                    lrow[g] = dl;
+                    acc_b[j] += dl;
+                    if (ZINB) {
+                        const float dp = -pj[j] * invB;
+                        prow[g] = dp;
+                        acc_p[j] += dp;
+                    }
+                }
+            }
+            const bool last = (b + 1 == b1);
+            const int cn = last ? -1 : (a.cond ? a.cond[b + 1] : 0);
+            if (last || cn != c) {
+                float* dst = a.dthetaT + (long long)c * G;
+#pragma unroll
+                for (int j = 0; j < EPT; ++j) {
+                    const int g = t + T * j;
+                    if (g < G) {
+                        atomicAdd(&dst[g], acc_th[j] + dx[g]);
+                        dx[g] = 0.f;
+                        acc_th[j] = 0.f;
+                    }
+                }
+            }
+        }
+    }
+    if (a.compute_grad) {
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int g = t + T * j;
+            if (g < G) {
+                if (a.dbias) atomicAdd(&a.dbias[g], acc_b[j]);
+                if (ZINB && a.dbias_pi) atomicAdd(&a.dbias_pi[g], acc_p[j]);
+            }
+        }
+    }
+}
+
+// MSE head: out = relu(lin), loss_b = sum_g (out - x)^2 ; d lin = 2 (out - x) / B where lin > 0.
+__global__ __launch_bounds__(256) void mse_rows_kernel(float* __restrict__ lin, int ldl, const float* __restrict__ x,
+                                                       int ldx, int B, int G, int rows_per_block,
+                                                       float* __restrict__ row_loss, float* __restrict__ dbias,
+                                                       int compute_grad) {
+    __shared__ float red[16];
+    const int b0 = blockIdx.x * rows_per_block, b1 = min(B, b0 + rows_per_block);
+    const float invB = 1.0f / (float)B;
+    for (int g0 = 0; g0 < G; g0 += 256) {
+        const int g = g0 + threadIdx.x;
+        float accb = 0.f;
+        for (int b = b0; b < b1; ++b) {
+            float sq = 0.f;
+            if (g < G) {
+                const float l = lin[(long long)b * ldl + g];
+                const float o = fmaxf(l, 0.f);
+                const float d = o - x[(long long)b * ldx + g];
+                sq = d * d;
+                if (compute_grad) {
+                    const float dl = l > 0.f ? 2.0f * d * invB : 0.f;
+                    lin[(long long)b * ldl + g] = dl;
+                    accb += dl;
+                }
+            }
+            sq = block_sum(sq, red);
+            if (threadIdx.x == 0) {
+                if (g0 == 0) row_loss[b] = sq;
+                else row_loss[b] += sq;
+            }
+        }
+        if (compute_grad && dbias && g < G) atomicAdd(&dbias[g], accb);
+    }
+}
+
+template <bool ZINB>
+int launch_recon(const ReconArgs& a, hipStream_t st) {
+    const int G = a.G;
+    const size_t shm = (size_t)(ZINB ? 3 : 2) * G * sizeof(float);
+    const int nblk = (a.B + a.rows_per_block - 1) / a.rows_per_block;
+#define RL(TT, EE)                                                                                         \
+    do {                                                                                                   \
+        if (shm > 48 * 1024)                                                                               \
+            hipFuncSetAttribute((const void*)recon_rows_kernel<TT, EE, ZINB>,                              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                     \
+        hipLaunchKernelGGL((recon_rows_kernel<TT, EE, ZINB>), dim3(nblk), dim3(TT), shm, st, a);           \
+    } while (0)
+    if (G <= 256 * 4) RL(256, 4);
+    else if (G <= 256 * 8) RL(256, 8);
+    else if (G <= 512 * 8) RL(512, 8);
+    else if (G <= 1024 * 8) RL(1024, 8);
+    else if (G <= 1024 * 12) RL(1024, 12);
+    else return -2;     // > 12288 genes: LDS extras (2-3 x G floats) no longer fit next to useful occupancy
+#undef RL
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int sca_theta_prep(const float* theta, int G, int C, float* tab_theta, float* tab_lte, void* stream) {
+    if (G * C <= 0) return 0;
+    hipLaunchKernelGGL(theta_prep_kernel, dim3((G * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, theta, G, C,
+                       tab_theta, tab_lte);
+    SCA_CHECK_LAUNCH();
+    return 0;
+}
+
+// dst[cols][rows] = scale * src[rows][cols]
+extern "C" int sca_transpose_scale(const float* src, int rows, int cols, float scale, float* dst, void* stream) {
+    if (rows * cols <= 0) return 0;
+    hipLaunchKernelGGL(transpose_scale_kernel, dim3((rows * cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, src,
+                       rows, cols, scale, dst);
+    SCA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sca_recon_rows(int zinb, float* logits, int ldl, float* pi, const int64_t* indptr,
+                              const int32_t* indices, const float* data, const int64_t* row_ids,
+                              const float* sizefactor, const int32_t* cond, const float* tab_theta,
+                              const float* tab_lte, int B, int G, int C, int rows_per_block, float* row_ll,
+                              float* dthetaT, float* dbias, float* dbias_pi, int compute_grad, void* stream) {
+    if (B <= 0) return 0;
+    if (rows_per_block < 1 || ldl < G) return -1;
+    ReconArgs a{logits, ldl, pi, indptr, indices, data, row_ids, sizefactor, cond, tab_theta, tab_lte,
+                B, G, C, rows_per_block, row_ll, dthetaT, dbias, dbias_pi, compute_grad};
+    const int rc = zinb ? launch_recon<true>(a, (hipStream_t)stream) : launch_recon<false>(a, (hipStream_t)stream);
+    if (rc) return rc;
+    SCA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sca_mse_rows(float* lin, int ldl, const float* x, int ldx, int B, int G, int rows_per_block,
+                            float* row_loss, float* dbias, int compute_grad, void* stream) {
+    if (B <= 0) return 0;
+    const int nblk = (B + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(mse_rows_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, lin, ldl, x, ldx, B, G,
+                       rows_per_block, row_loss, dbias, compute_grad);
+    SCA_CHECK_LAUNCH();
+    return 0;
+}

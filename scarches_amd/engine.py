@@ -1,0 +1,531 @@
+"""Host-side driver of the HIP conditional-VAE step (trVAE family).
+
+Owns the flat parameter / gradient / Adam-state buffers in HBM, the per-batch workspaces, and the launch order of the
+kernels behind the C ABI (include/scarches_hip.h).  PyTorch is used for device memory, streams and (elsewhere)
+torch.distributed only; all arithmetic of the step runs in libscarches_hip.so.  There is no CPU fallback.
+
+Reference path reproduced (see the kernel files for line-level citations):
+  scarches/models/trvae/trvae.py:116-157 (forward), trainers/trvae/unsupervised.py:62-64 (loss composition),
+  trainers/trvae/trainer.py:221-223,262-280 (Adam + iteration), models/base/_base.py:409-455 (get_latent / get_y).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+ALIGN = 64  # floats (256 B) - every tensor starts on its own 256-byte boundary inside the flat buffers
+
+
+def _round_up(n, a):
+    return (n + a - 1) // a * a
+
+
+class _Layer:
+    __slots__ = ("tag", "w", "b", "wc", "n_in", "n_out", "rng_stream", "mask_key")
+
+    def __init__(self, tag, w, b, wc, n_in, n_out, rng_stream, mask_key):
+        self.tag, self.w, self.b, self.wc = tag, w, b, wc
+        self.n_in, self.n_out, self.rng_stream, self.mask_key = n_in, n_out, rng_stream, mask_key
+
+
+class CVAEEngine:
+    """Forward / backward / Adam of a trVAE-style conditional VAE on one MI355X."""
+
+    def __init__(self, spec: dict, named_params: "OrderedDict[str, torch.Tensor]", device):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.HipLibraryError("scarches_amd runs on a HIP device only (no CPU fallback)")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        s = dict(spec)
+        self.G, self.C, self.H, self.Z = int(s["G"]), int(s["C"]), list(s["H"]), int(s["Z"])
+        self.recon = s["recon"]
+        self.use_bn, self.use_ln = bool(s.get("use_bn", False)), bool(s.get("use_ln", True))
+        if self.use_bn:
+            raise NotImplementedError("use_bn=True (BatchNorm1d) is not built yet in the HIP path; use use_ln")
+        self.norm = 1 if self.use_ln else 0
+        self.dr_rate = float(s.get("dr_rate", 0.0))
+        self.use_mmd = bool(s.get("use_mmd", False))
+        self.mmd_on = s.get("mmd_on", "z")
+        self.boundary = s.get("boundary", None)
+        self.beta = float(s.get("beta", 1.0))
+        self.seed = int(s.get("seed", 2020))
+        assert self.recon in ("nb", "zinb", "mse")
+        assert len(self.H) >= 1, "at least one hidden layer is required"
+
+        # ---- flat parameter storage ------------------------------------------------------------------------
+        # mean/log_var heads are stored back to back so that both run as ONE [2Z, H] GEMM
+        order = list(named_params.keys())
+        fused = ["encoder.mean_encoder.weight", "encoder.log_var_encoder.weight",
+                 "encoder.mean_encoder.bias", "encoder.log_var_encoder.bias"]
+        order = [k for k in order if k not in fused]
+        self.offsets: Dict[str, int] = {}
+        self.shapes: Dict[str, tuple] = {}
+        off = 0
+        for k in order:
+            self.offsets[k] = off
+            self.shapes[k] = tuple(named_params[k].shape)
+            off = _round_up(off + named_params[k].numel(), ALIGN)
+        for pair in (fused[:2], fused[2:]):
+            for k in pair:
+                self.offsets[k] = off
+                self.shapes[k] = tuple(named_params[k].shape)
+                off += named_params[k].numel()
+            off = _round_up(off, ALIGN)
+        self.n_flat = off
+        self.names = list(named_params.keys())
+        dev = self.device
+        self.flat_p = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.p: Dict[str, torch.Tensor] = {}
+        self.g: Dict[str, torch.Tensor] = {}
+        for k in self.names:
+            o, n = self.offsets[k], int(np.prod(self.shapes[k]))
+            self.p[k] = self.flat_p[o:o + n].view(self.shapes[k])
+            self.g[k] = self.flat_g[o:o + n].view(self.shapes[k])
+            self.p[k].copy_(named_params[k].detach().to(torch.float32))
+        self.trainable = {k: True for k in self.names}
+        self.adam_t = 0
+
+        # ---- layer table -----------------------------------------------------------------------------------
+        H, G, Z = self.H, self.G, self.Z
+        has_c = self.C > 0
+        self.enc: List[_Layer] = []
+        for i, h in enumerate(H):
+            if i == 0:
+                self.enc.append(_Layer(f"enc{i}", "encoder.FC.L0.expr_L.weight", "encoder.FC.L0.expr_L.bias",
+                                       "encoder.FC.L0.cond_L.weight" if has_c else None, G, h, 10 + i, f"enc{i}"))
+            else:
+                self.enc.append(_Layer(f"enc{i}", f"encoder.FC.L{i}.weight", f"encoder.FC.L{i}.bias", None,
+                                       H[i - 1], h, 10 + i, f"enc{i}"))
+        Hd = list(reversed(H))
+        self.dec: List[_Layer] = [_Layer("dec0", "decoder.FirstL.L0.expr_L.weight", None,
+                                         "decoder.FirstL.L0.cond_L.weight" if has_c else None, Z, Hd[0], 40, "dec0")]
+        for i in range(1, len(Hd)):
+            self.dec.append(_Layer(f"dec{i}", f"decoder.HiddenL.L{i}.weight", None, None, Hd[i - 1], Hd[i], 40 + i,
+                                   f"dec{i}"))
+        if self.recon == "mse":
+            self.out_w, self.out_b = "decoder.recon_decoder.0.weight", "decoder.recon_decoder.0.bias"
+        else:
+            self.out_w, self.out_b = "decoder.mean_decoder.0.weight", "decoder.mean_decoder.0.bias"
+        self.heads_w = self.flat_p[self.offsets[fused[0]]:self.offsets[fused[0]] + 2 * Z * H[-1]].view(2 * Z, H[-1])
+        self.heads_b = self.flat_p[self.offsets[fused[2]]:self.offsets[fused[2]] + 2 * Z]
+        self.heads_gw = self.flat_g[self.offsets[fused[0]]:self.offsets[fused[0]] + 2 * Z * H[-1]].view(2 * Z, H[-1])
+        self.heads_gb = self.flat_g[self.offsets[fused[2]]:self.offsets[fused[2]] + 2 * Z]
+
+        # ---- small persistent device state -----------------------------------------------------------------
+        self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
+        # pinned staging ring: an async H2D copy reads host memory when it executes, so each in-flight
+        # update needs its own slot (an event per slot guards reuse)
+        self._hyper_host = torch.zeros(8, dtype=torch.float32)
+        self._hyper_ring = torch.zeros(64, 8, dtype=torch.float32).pin_memory()
+        self._hyper_ev = [None] * 64
+        self._hyper_i = 0
+        self.step_ctr = torch.zeros(1, dtype=torch.int32, device=dev)      # mixed into the Philox streams
+        self.losses = torch.zeros(4, dtype=torch.float32, device=dev)
+        self.accum = torch.zeros(5, dtype=torch.float64, device=dev)
+        self.csr = None
+        self.Bcap = 0
+        self.set_hyper(alpha_kl=1.0, lr=1e-3, eps=0.01, clip=0.0)
+
+    # ------------------------------------------------------------------------------------------ configuration
+    def set_hyper(self, alpha_kl=None, lr=None, eps=None, clip=None, t=None):
+        h = self._hyper_host
+        if alpha_kl is not None:
+            h[0] = float(alpha_kl)
+        if lr is not None:
+            h[1] = float(lr)
+        if t is not None:
+            h[2] = 1.0 - 0.9 ** t
+            h[3] = math.sqrt(1.0 - 0.999 ** t)
+        if eps is not None:
+            h[4] = float(eps)
+        if clip is not None:
+            h[5] = float(clip)
+        i = self._hyper_i = (self._hyper_i + 1) % 64
+        if self._hyper_ev[i] is not None:
+            self._hyper_ev[i].synchronize()
+        self._hyper_ring[i].copy_(h)
+        self.hyper.copy_(self._hyper_ring[i], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._hyper_ev[i] = ev
+
+    def bind_csr(self, indptr: torch.Tensor, indices: torch.Tensor, data: torch.Tensor):
+        """CSR matrix resident in HBM: indptr int64 [N+1], indices int32 [nnz], data float32 [nnz]."""
+        assert indptr.dtype == torch.int64 and indices.dtype == torch.int32 and data.dtype == torch.float32
+        assert indptr.device == self.device and indices.device == self.device and data.device == self.device
+        self.csr = (indptr.contiguous(), indices.contiguous(), data.contiguous())
+
+    def set_trainable(self, names):
+        names = set(names)
+        for k in self.names:
+            self.trainable[k] = k in names
+
+    # ------------------------------------------------------------------------------------------ workspaces
+    def _ensure(self, B):
+        if B <= self.Bcap:
+            return
+        dev, f32 = self.device, torch.float32
+        G, C, Z, H = self.G, max(self.C, 1), self.Z, self.H
+        L = self.lib
+        Hmax = max(H)
+        ws = {}
+        ws["x"] = torch.empty(B, G, dtype=f32, device=dev)
+        ws["sf"] = torch.empty(B, dtype=f32, device=dev)
+        for ly in self.enc + self.dec:
+            ws[ly.tag + ".yn"] = torch.empty(B, ly.n_out, dtype=f32, device=dev)
+            ws[ly.tag + ".rs"] = torch.empty(B, dtype=f32, device=dev)
+            ws[ly.tag + ".h"] = torch.empty(B, ly.n_out, dtype=f32, device=dev)
+        ws["mu_lv"] = torch.empty(B, 2 * Z, dtype=f32, device=dev)
+        ws["eps"] = torch.empty(B, Z, dtype=f32, device=dev)
+        ws["z"] = torch.empty(B, Z, dtype=f32, device=dev)
+        ws["kl_row"] = torch.empty(B, dtype=f32, device=dev)
+        ws["row_ll"] = torch.empty(B, dtype=f32, device=dev)
+        ws["logits"] = torch.empty(B, G, dtype=f32, device=dev)
+        if self.recon == "zinb":
+            ws["pi"] = torch.empty(B, G, dtype=f32, device=dev)
+        ws["tab_theta"] = torch.empty(C, G, dtype=f32, device=dev)
+        ws["tab_lte"] = torch.empty(C, G, dtype=f32, device=dev)
+        ws["dthetaT"] = torch.empty(C, G, dtype=f32, device=dev)
+        ws["segT"] = torch.empty(C * max(Hmax, 2 * Z), dtype=f32, device=dev)
+        ws["da"] = torch.empty(B, max(Hmax, 2 * Z), dtype=f32, device=dev)
+        ws["dheads"] = torch.empty(B, 2 * Z, dtype=f32, device=dev)
+        # split-K slab workspace: the largest S*M*N over every GEMM of the step
+        need = 0
+        shapes = []
+        for ly in self.enc + self.dec:
+            shapes += [(B, ly.n_out, ly.n_in), (ly.n_out, ly.n_in, B), (B, ly.n_in, ly.n_out)]
+        shapes += [(B, 2 * Z, H[-1]), (2 * Z, H[-1], B), (B, H[-1], 2 * Z)]
+        Hl = self.dec[-1].n_out
+        shapes += [(G, Hl, B), (B, Hl, G)]
+        for (M, N, K) in shapes:
+            need = max(need, L.sca_gemm_splitk_heuristic(M, N, K) * M * N)
+        ws["slab"] = torch.empty(need, dtype=f32, device=dev)
+        Dm = Z if self.mmd_on == "z" else self.dec[0].n_out
+        self._mmd_ns = L.sca_mmd_num_slabs(B, Dm)
+        ws["mmd_g"] = torch.empty(max(1, self._mmd_ns) * B * Dm, dtype=f32, device=dev)
+        ws["mmd_part"] = torch.zeros(max(1, L.sca_mmd_num_partials(B, Dm)), dtype=torch.float64, device=dev)
+        ws["mmd_extra"] = torch.empty(B, Dm, dtype=f32, device=dev)
+        ws["Wt"] = torch.empty(C * C, dtype=f32, device=dev)
+        ws["counts"] = torch.empty(C, dtype=torch.int32, device=dev)
+        self.ws = ws
+        self.Bcap = B
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def _gemm(self, am, bm, A, lda, Bm, ldb, M, N, K, st, out=None, ldc=None, bias=None, force_s1=False):
+        """Launch one GEMM; returns (ptr, S, slab_stride).  S == 1 with `out` writes the final tensor directly."""
+        L = self.lib
+        S = 1 if force_s1 else L.sca_gemm_splitk_heuristic(M, N, K)
+        if S == 1 and out is not None:
+            _lib.check(L.sca_gemm_f32(am, bm, A, lda, Bm, ldb, out, ldc or N, M, N, K, 1, 0, bias, st), "gemm")
+            return out, 1, 0
+        slab = self.ws["slab"].data_ptr()
+        _lib.check(L.sca_gemm_f32(am, bm, A, lda, Bm, ldb, slab, N, M, N, K, S, M * N, None, st), "gemm")
+        return slab, S, M * N
+
+    def _gemm_to(self, am, bm, A, lda, Bm, ldb, M, N, K, st, dst):
+        """GEMM whose (reduced) result lands in the contiguous tensor `dst` [M, N]."""
+        L = self.lib
+        p, S, stride = self._gemm(am, bm, A, lda, Bm, ldb, M, N, K, st, out=dst.data_ptr(), ldc=N)
+        if p != dst.data_ptr():
+            _lib.check(L.sca_splitk_reduce(p, S, stride, dst.data_ptr(), M * N, st), "splitk_reduce")
+
+    # ------------------------------------------------------------------------------------------ the step
+    def forward_backward(self, row_ids: Optional[torch.Tensor], cond: Optional[torch.Tensor], B: int, train=True,
+                         compute_grad=True, eps: Optional[torch.Tensor] = None,
+                         masks: Optional[Dict[str, torch.Tensor]] = None, accumulate_logs=True,
+                         x_dense: Optional[torch.Tensor] = None):
+        """One fwd(+bwd) pass over the minibatch `row_ids` (int64 device tensor of CSR row numbers) whose conditions
+        are `cond` (int32 device tensor).  Leaves losses in self.losses = [recon, kl, mmd, total] and, when
+        compute_grad, the gradients of recon + hyper[0]*kl + mmd in self.flat_g.  Nothing is synchronised."""
+        L, P = self.lib, self.p
+        self._ensure(B)
+        ws = self.ws
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        G, C, Z = self.G, self.C, self.Z
+        ptr = _lib.ptr
+        p_drop = self.dr_rate if train else 0.0
+        cond_p = ptr(cond) if C > 0 else None
+        step_p = self.step_ctr.data_ptr()
+        masks = masks or {}
+
+        # 1. minibatch gather (+ log1p, size factors)
+        log1p = 0 if self.recon == "mse" else 1
+        if x_dense is not None:
+            _lib.check(L.sca_dense_gather_rows(ptr(x_dense), x_dense.stride(0), ptr(row_ids), B, G, log1p,
+                                               ws["x"].data_ptr(), G, ws["sf"].data_ptr(), st), "dense_gather")
+        else:
+            ip, ix, dv = self.csr
+            _lib.check(L.sca_csr_gather_rows(ip.data_ptr(), ix.data_ptr(), dv.data_ptr(), ptr(row_ids), B, G, log1p,
+                                             ws["x"].data_ptr(), G, ws["sf"].data_ptr(), st), "csr_gather")
+
+        def layer_forward(ly, a_in):
+            sp, S, stride = self._gemm(0, 0, a_in, ly.n_in, P[ly.w].data_ptr(), ly.n_in, B, ly.n_out, ly.n_in, st)
+            m = masks.get(ly.mask_key)
+            _lib.check(L.sca_layer_fwd(sp, S, stride, B, ly.n_out, ptr(P[ly.b]) if ly.b else None,
+                                       ptr(P[ly.wc]) if ly.wc else None, C, cond_p, None, 0, self.norm, 1, p_drop,
+                                       ptr(m), self.seed, ly.rng_stream, step_p, ws[ly.tag + ".yn"].data_ptr(),
+                                       ws[ly.tag + ".rs"].data_ptr(), ws[ly.tag + ".h"].data_ptr(), st), "layer_fwd")
+            return ws[ly.tag + ".h"].data_ptr()
+
+        # 2. encoder
+        a = ws["x"].data_ptr()
+        for ly in self.enc:
+            a = layer_forward(ly, a)
+        # 3. heads + sampling + KL
+        Hl = self.H[-1]
+        sp, S, stride = self._gemm(0, 0, a, Hl, self.heads_w.data_ptr(), Hl, B, 2 * Z, Hl, st)
+        _lib.check(L.sca_latent_fwd(sp, S, stride, self.heads_b.data_ptr(), B, Z, ptr(eps), self.seed, 1, step_p, 1,
+                                    ws["mu_lv"].data_ptr(), ws["eps"].data_ptr(), ws["z"].data_ptr(),
+                                    ws["kl_row"].data_ptr(), st), "latent_fwd")
+        # 4. decoder
+        a = ws["z"].data_ptr()
+        for ly in self.dec:
+            a = layer_forward(ly, a)
+        Hd = self.dec[-1].n_out
+        # 5. output layer + reconstruction loss (+ gradient w.r.t. the logits, in place)
+        self._gemm(0, 0, a, Hd, P[self.out_w].data_ptr(), Hd, B, G, Hd, st, out=ws["logits"].data_ptr(), ldc=G,
+                   bias=P[self.out_b].data_ptr(), force_s1=True)
+        if compute_grad:
+            self.flat_g.zero_()
+        rpb = max(1, B // 1024)
+        if self.recon == "mse":
+            _lib.check(L.sca_mse_rows(ws["logits"].data_ptr(), G, ws["x"].data_ptr(), G, B, G, rpb,
+                                      ws["row_ll"].data_ptr(),
+                                      self.g[self.out_b].data_ptr() if self.trainable[self.out_b] else None,
+                                      int(compute_grad), st),
+                       "mse_rows")
+            recon_sign = 1.0
+        else:
+            zinb = self.recon == "zinb"
+            if zinb:
+                self._gemm(0, 0, a, Hd, P["decoder.dropout_decoder.weight"].data_ptr(), Hd, B, G, Hd, st,
+                           out=ws["pi"].data_ptr(), ldc=G, bias=P["decoder.dropout_decoder.bias"].data_ptr(),
+                           force_s1=True)
+            _lib.check(L.sca_theta_prep(P["theta"].data_ptr(), G, max(C, 1), ws["tab_theta"].data_ptr(),
+                                        ws["tab_lte"].data_ptr(), st), "theta_prep")
+            if compute_grad:
+                ws["dthetaT"].zero_()
+            ip, ix, dv = self.csr
+            _lib.check(L.sca_recon_rows(int(zinb), ws["logits"].data_ptr(), G, ws["pi"].data_ptr() if zinb else None,
+                                        ip.data_ptr(), ix.data_ptr(), dv.data_ptr(), ptr(row_ids),
+                                        ws["sf"].data_ptr(), cond_p, ws["tab_theta"].data_ptr(),
+                                        ws["tab_lte"].data_ptr(), B, G, max(C, 1), rpb, ws["row_ll"].data_ptr(),
+                                        ws["dthetaT"].data_ptr(),
+                                        self.g[self.out_b].data_ptr() if self.trainable[self.out_b] else None,
+                                        self.g["decoder.dropout_decoder.bias"].data_ptr()
+                                        if zinb and self.trainable["decoder.dropout_decoder.bias"] else None,
+                                        int(compute_grad), st), "recon_rows")
+            recon_sign = -1.0
+        # 6. MMD (value + gradient w.r.t. z or y1)
+        n_part = 0
+        if self.use_mmd and C > 0:
+            feat, Dm = (ws["z"], Z) if self.mmd_on == "z" else (ws["dec0.h"], self.dec[0].n_out)
+            ns = L.sca_mmd_num_slabs(B, Dm)
+            n_part = L.sca_mmd_num_partials(B, Dm)
+            _lib.check(L.sca_mmd_fwd_bwd(feat.data_ptr(), Dm, cond_p, B, Dm, C,
+                                         -1 if self.boundary is None else int(self.boundary), self.beta,
+                                         ws["Wt"].data_ptr(), ws["counts"].data_ptr(), ws["mmd_part"].data_ptr(),
+                                         ws["mmd_g"].data_ptr() if compute_grad else None, B * Dm, st), "mmd")
+            self._mmd_ns_cur = ns
+        _lib.check(L.sca_finalize_losses(ws["row_ll"].data_ptr(), recon_sign, ws["kl_row"].data_ptr(), B,
+                                         ws["mmd_part"].data_ptr(), n_part, self.hyper.data_ptr(),
+                                         self.losses.data_ptr(), self.accum.data_ptr() if accumulate_logs else None,
+                                         st), "finalize_losses")
+        if not compute_grad:
+            return self.losses
+        self._backward(B, cond_p, p_drop, masks, st, n_part > 0)
+        return self.losses
+
+    def _backward(self, B, cond_p, p_drop, masks, st, have_mmd):
+        L, P, Gd, ws, T = self.lib, self.p, self.g, self.ws, self.trainable
+        G, C, Z = self.G, self.C, self.Z
+        ptr = _lib.ptr
+        step_p = self.step_ctr.data_ptr()
+        # theta gradient: -1/B * sum_b theta dll/dtheta, transposed back to the [G][C] parameter layout
+        if self.recon != "mse" and T["theta"]:
+            _lib.check(L.sca_transpose_scale(ws["dthetaT"].data_ptr(), max(C, 1), G, -1.0 / B,
+                                             Gd["theta"].data_ptr(), st), "transpose_scale")
+        # output layer(s)
+        Hd = self.dec[-1].n_out
+        h_last = ws[self.dec[-1].tag + ".h"].data_ptr()
+        dl = ws["logits"].data_ptr()
+        if T[self.out_w]:
+            self._gemm_to(1, 1, dl, G, h_last, Hd, G, Hd, B, st, Gd[self.out_w])
+        # dX of the output layer (+ the ZINB dropout head, which shares the input): slabs feed the next layer_bwd
+        if self.recon == "zinb":
+            dp = ws["pi"].data_ptr()
+            if T["decoder.dropout_decoder.weight"]:
+                self._gemm_to(1, 1, dp, G, h_last, Hd, G, Hd, B, st, Gd["decoder.dropout_decoder.weight"])
+            # dh = dl @ Wo + dpi @ Wp : the second product is reduced into a scratch [B, Hd] and joins as `extra`
+            scratch = self._scratch_bh(B, Hd)
+            self._gemm_to(0, 1, dp, G, P["decoder.dropout_decoder.weight"].data_ptr(), Hd, B, Hd, G, st, scratch)
+            extra = scratch.data_ptr()
+        else:
+            extra = None
+        sp, S, stride = self._gemm(0, 1, dl, G, P[self.out_w].data_ptr(), Hd, B, Hd, G, st)
+
+        # decoder, last -> first
+        for li in range(len(self.dec) - 1, -1, -1):
+            ly = self.dec[li]
+            if li == 0 and have_mmd and self.mmd_on == "y":
+                # gradient of the MMD on y1 joins the upstream gradient of the first decoder layer
+                _lib.check(L.sca_splitk_reduce(ws["mmd_g"].data_ptr(), self._mmd_ns_cur, B * ly.n_out,
+                                               ws["mmd_extra"].data_ptr(), B * ly.n_out, st), "mmd_reduce")
+                if extra is not None:       # single-hidden-layer ZINB net: both extras land on the same layer
+                    ws["mmd_extra"].view(-1)[:B * ly.n_out].add_(self._scratch_bh(B, ly.n_out).view(-1))
+                extra = ws["mmd_extra"].data_ptr()
+            m = masks.get(ly.mask_key)
+            da = ws["da"].data_ptr()
+            _lib.check(L.sca_layer_bwd(sp, S, stride, extra, B, ly.n_out, ws[ly.tag + ".yn"].data_ptr(),
+                                       ws[ly.tag + ".rs"].data_ptr(), self.norm, 1, p_drop, ptr(m), self.seed,
+                                       ly.rng_stream, step_p, da, st), "layer_bwd")
+            extra = None
+            a_prev = ws["z"].data_ptr() if li == 0 else ws[self.dec[li - 1].tag + ".h"].data_ptr()
+            if T[ly.w]:
+                self._gemm_to(1, 1, da, ly.n_out, a_prev, ly.n_in, ly.n_out, ly.n_in, B, st, Gd[ly.w])
+            if ly.wc and T[ly.wc]:
+                _lib.check(L.sca_cond_colsum(da, B, ly.n_out, cond_p, C, ws["segT"].data_ptr(),
+                                             Gd[ly.wc].data_ptr(), None, st), "cond_colsum")
+            sp, S, stride = self._gemm(0, 1, da, ly.n_out, P[ly.w].data_ptr(), ly.n_in, B, ly.n_in, ly.n_out, st)
+
+        # latent block: dz (decoder) + dz (MMD on z) + KL
+        use_mz = have_mmd and self.mmd_on == "z"
+        _lib.check(L.sca_latent_bwd(sp, S, stride, ws["mmd_g"].data_ptr() if use_mz else None,
+                                    self._mmd_ns_cur if use_mz else 0, B * Z, ws["mu_lv"].data_ptr(),
+                                    ws["eps"].data_ptr(), self.hyper.data_ptr(), B, Z, ws["dheads"].data_ptr(), st),
+                   "latent_bwd")
+        Hl = self.H[-1]
+        h_enc = ws[self.enc[-1].tag + ".h"].data_ptr()
+        dh = ws["dheads"].data_ptr()
+        heads_train = T["encoder.mean_encoder.weight"]
+        if heads_train:
+            self._gemm_to(1, 1, dh, 2 * Z, h_enc, Hl, 2 * Z, Hl, B, st, self.heads_gw)
+            _lib.check(L.sca_cond_colsum(dh, B, 2 * Z, None, 0, ws["segT"].data_ptr(), None,
+                                         self.heads_gb.data_ptr(), st), "heads_bias")
+        sp, S, stride = self._gemm(0, 1, dh, 2 * Z, self.heads_w.data_ptr(), Hl, B, Hl, 2 * Z, st)
+
+        # encoder, last -> first
+        for li in range(len(self.enc) - 1, -1, -1):
+            ly = self.enc[li]
+            m = masks.get(ly.mask_key)
+            da = ws["da"].data_ptr()
+            _lib.check(L.sca_layer_bwd(sp, S, stride, None, B, ly.n_out, ws[ly.tag + ".yn"].data_ptr(),
+                                       ws[ly.tag + ".rs"].data_ptr(), self.norm, 1, p_drop, ptr(m), self.seed,
+                                       ly.rng_stream, step_p, da, st), "layer_bwd")
+            a_prev = ws["x"].data_ptr() if li == 0 else ws[self.enc[li - 1].tag + ".h"].data_ptr()
+            if T[ly.w]:
+                self._gemm_to(1, 1, da, ly.n_out, a_prev, ly.n_in, ly.n_out, ly.n_in, B, st, Gd[ly.w])
+            need_b = ly.b and T[ly.b]
+            need_c = ly.wc and T[ly.wc]
+            if need_b or need_c:
+                _lib.check(L.sca_cond_colsum(da, B, ly.n_out, cond_p if ly.wc else None, C if ly.wc else 0,
+                                             ws["segT"].data_ptr(), Gd[ly.wc].data_ptr() if need_c else None,
+                                             Gd[ly.b].data_ptr() if need_b else None, st), "cond_colsum")
+            if li > 0:
+                sp, S, stride = self._gemm(0, 1, da, ly.n_out, P[ly.w].data_ptr(), ly.n_in, B, ly.n_in, ly.n_out, st)
+
+    def _scratch_bh(self, B, Hd):
+        if not hasattr(self, "_sbh") or self._sbh.numel() < B * Hd:
+            self._sbh = torch.empty(B * Hd, dtype=torch.float32, device=self.device)
+        return self._sbh[:B * Hd].view(B, Hd)
+
+    # ------------------------------------------------------------------------------------------ optimiser
+    def trainable_ranges(self):
+        """Contiguous [start, end) ranges of the flat buffer covering the trainable tensors (merged)."""
+        spans = sorted((self.offsets[k], self.offsets[k] + int(np.prod(self.shapes[k]))) for k in self.names
+                       if self.trainable[k])
+        merged = []
+        for s, e in spans:
+            if merged and s <= _round_up(merged[-1][1], ALIGN):
+                merged[-1][1] = e
+            else:
+                merged.append([s, e])
+        return [(s, e) for s, e in merged]
+
+    def adam_step(self, weight_decay=0.04, wd_overrides: Optional[Dict[str, float]] = None):
+        """One torch.optim.Adam-equivalent update of every trainable tensor; hyper[] must hold lr / bias corrections
+        for step t = self.adam_t + 1 (call begin_step first)."""
+        L = self.lib
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        if wd_overrides:
+            # per-tensor weight decay (scPoli: embeddings 0): one launch per tensor
+            for k in self.names:
+                if not self.trainable[k]:
+                    continue
+                o, n = self.offsets[k], int(np.prod(self.shapes[k]))
+                wd = wd_overrides.get(k, weight_decay)
+                _lib.check(L.sca_adam_step(self.flat_p[o:].data_ptr(), self.flat_g[o:].data_ptr(),
+                                           self.flat_m[o:].data_ptr(), self.flat_v[o:].data_ptr(), n,
+                                           self.hyper.data_ptr(), 0.9, 0.999, wd, st), "adam")
+            return
+        for s, e in self.trainable_ranges():
+            _lib.check(L.sca_adam_step(self.flat_p[s:].data_ptr(), self.flat_g[s:].data_ptr(),
+                                       self.flat_m[s:].data_ptr(), self.flat_v[s:].data_ptr(), e - s,
+                                       self.hyper.data_ptr(), 0.9, 0.999, weight_decay, st), "adam")
+
+    def begin_step(self, alpha_kl, lr, eps=0.01, clip=0.0):
+        self.adam_t += 1
+        self.set_hyper(alpha_kl=alpha_kl, lr=lr, eps=eps, clip=clip, t=self.adam_t)
+        self.step_ctr += 1
+
+    # ------------------------------------------------------------------------------------------ inference
+    def encode(self, row_ids, cond, B, mean=True, x_dense=None, eps=None):
+        """Eval-mode encoder pass: returns (z or mean [B,Z], mean, var) device tensors (views of the workspace)."""
+        L, P = self.lib, self.p
+        self._ensure(B)
+        ws = self.ws
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        ptr = _lib.ptr
+        G, C, Z = self.G, self.C, self.Z
+        log1p = 0 if self.recon == "mse" else 1
+        if x_dense is not None:
+            _lib.check(L.sca_dense_gather_rows(ptr(x_dense), x_dense.stride(0), ptr(row_ids), B, G, log1p,
+                                               ws["x"].data_ptr(), G, ws["sf"].data_ptr(), st), "dense_gather")
+        else:
+            ip, ix, dv = self.csr
+            _lib.check(L.sca_csr_gather_rows(ip.data_ptr(), ix.data_ptr(), dv.data_ptr(), ptr(row_ids), B, G, log1p,
+                                             ws["x"].data_ptr(), G, ws["sf"].data_ptr(), st), "csr_gather")
+        a = ws["x"].data_ptr()
+        cond_p = ptr(cond) if C > 0 else None
+        for ly in self.enc:
+            sp, S, stride = self._gemm(0, 0, a, ly.n_in, P[ly.w].data_ptr(), ly.n_in, B, ly.n_out, ly.n_in, st)
+            _lib.check(L.sca_layer_fwd(sp, S, stride, B, ly.n_out, ptr(P[ly.b]) if ly.b else None,
+                                       ptr(P[ly.wc]) if ly.wc else None, C, cond_p, None, 0, self.norm, 1, 0.0, None,
+                                       self.seed, ly.rng_stream, None, ws[ly.tag + ".yn"].data_ptr(),
+                                       ws[ly.tag + ".rs"].data_ptr(), ws[ly.tag + ".h"].data_ptr(), st), "layer_fwd")
+            a = ws[ly.tag + ".h"].data_ptr()
+        Hl = self.H[-1]
+        sp, S, stride = self._gemm(0, 0, a, Hl, self.heads_w.data_ptr(), Hl, B, 2 * Z, Hl, st)
+        self.step_ctr += 1          # fresh noise for every sampled pass
+        _lib.check(L.sca_latent_fwd(sp, S, stride, self.heads_b.data_ptr(), B, Z, ptr(eps), self.seed, 2,
+                                    self.step_ctr.data_ptr(), 0 if mean else 1, ws["mu_lv"].data_ptr(),
+                                    ws["eps"].data_ptr(), ws["z"].data_ptr(), ws["kl_row"].data_ptr(), st),
+                   "latent_fwd")
+        mu = ws["mu_lv"][:B, :Z]
+        var = torch.exp(ws["mu_lv"][:B, Z:]) + 1e-4
+        return ws["z"][:B], mu, var
+
+    def decode_first_layer(self, cond, B):
+        """y1 = first decoder block applied to the current ws['z'] (eval mode): get_y()."""
+        L, P, ws = self.lib, self.p, self.ws
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        ly = self.dec[0]
+        ptr = _lib.ptr
+        sp, S, stride = self._gemm(0, 0, ws["z"].data_ptr(), ly.n_in, P[ly.w].data_ptr(), ly.n_in, B, ly.n_out,
+                                   ly.n_in, st)
+        _lib.check(L.sca_layer_fwd(sp, S, stride, B, ly.n_out, None, ptr(P[ly.wc]) if ly.wc else None, self.C,
+                                   ptr(cond) if self.C > 0 else None, None, 0, self.norm, 1, 0.0, None, self.seed,
+                                   ly.rng_stream, None, ws[ly.tag + ".yn"].data_ptr(), ws[ly.tag + ".rs"].data_ptr(),
+                                   ws[ly.tag + ".h"].data_ptr(), st), "layer_fwd")
+        return ws[ly.tag + ".h"][:B]

@@ -1,0 +1,255 @@
+"""GPU parity of the individual HIP entry points (through the C ABI) against the oracle / golden vectors."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from tests._util import GOLDEN, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from scarches_amd import _lib
+    return _lib.load()
+
+
+_KEEP = []
+
+
+def dev(a, dtype=None):
+    """Host array -> device tensor that stays alive until the end of the test (see _release)."""
+    t = torch.as_tensor(a)
+    if dtype is not None:
+        t = t.to(dtype)
+    t = t.cuda().contiguous()
+    _KEEP.append(t)
+    return t
+
+
+@pytest.fixture(autouse=True)
+def _release():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (257, 130, 77), (16, 2000, 128), (4096, 128, 2000),
+                                   (7, 5, 3), (512, 20, 128), (300, 10, 128)])
+@pytest.mark.parametrize("mode", [(0, 0), (0, 1), (1, 1)])
+def test_gemm_modes(lib, M, N, K, mode):
+    from scarches_amd import _lib
+    am, bm = mode
+    g = torch.Generator().manual_seed(M * 31 + N * 7 + K)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(K, N, generator=g)
+    ref = (A.double() @ Bm.double())
+    Ad = dev(A if am == 0 else A.t())           # mode 1 stores A as [K][M]
+    Bd = dev(Bm.t() if bm == 0 else Bm)         # mode 0 stores B as [N][K]
+    lda = K if am == 0 else M
+    ldb = K if bm == 0 else N
+    for S in sorted({1, lib.sca_gemm_splitk_heuristic(M, N, K), 3}):
+        slabs = torch.full((S, M, N), float("nan"), device="cuda")
+        _lib.check(lib.sca_gemm_f32(am, bm, Ad.data_ptr(), lda, Bd.data_ptr(), ldb, slabs.data_ptr(), N, M, N, K, S,
+                                    M * N, None, st()), "gemm")
+        out = torch.empty(M, N, device="cuda")
+        _lib.check(lib.sca_splitk_reduce(slabs.data_ptr(), S, M * N, out.data_ptr(), M * N, st()), "reduce")
+        torch.cuda.synchronize()
+        err = (out.cpu().double() - ref).abs().max().item()
+        scale = (A.abs().double() @ Bm.abs().double()).max().item()
+        assert err <= 2e-6 * scale, (S, err, scale)
+
+
+def test_gemm_bias_and_unaligned(lib):
+    from scarches_amd import _lib
+    M, N, K = 33, 50, 19           # lda/ldb not multiples of 4 -> scalar staging path
+    A, W, b = torch.randn(M, K), torch.randn(N, K), torch.randn(N)
+    out = torch.empty(M, N, device="cuda")
+    _lib.check(lib.sca_gemm_f32(0, 0, dev(A).data_ptr(), K, dev(W).data_ptr(), K, out.data_ptr(), N, M, N, K, 1, 0,
+                                dev(b).data_ptr(), st()), "gemm")
+    ref = A.double() @ W.double().t() + b.double()
+    assert (out.cpu().double() - ref).abs().max().item() < 1e-5
+
+
+def test_csr_gather(lib):
+    from scarches_amd import _lib
+    from oracle import cvae_oracle as O
+    z = np.load(GOLDEN + "/host.npz")
+    n, G = (int(v) for v in z["ds_shape"])
+    rows = np.array([3, 10, 11, 40, 0, n - 1, 10], dtype=np.int64)
+    x_ref, sf_ref = O.csr_rows_to_dense(z["ds_x_indptr"], z["ds_x_indices"], z["ds_x_data"], rows, G)
+    for log1p in (0, 1):
+        out = torch.full((len(rows), G), float("nan"), device="cuda")
+        sf = torch.empty(len(rows), device="cuda")
+        _lib.check(lib.sca_csr_gather_rows(dev(z["ds_x_indptr"]).data_ptr(), dev(z["ds_x_indices"]).data_ptr(),
+                                           dev(z["ds_x_data"]).data_ptr(), dev(rows).data_ptr(), len(rows), G, log1p,
+                                           out.data_ptr(), G, sf.data_ptr(), st()), "gather")
+        torch.cuda.synchronize()
+        ref = torch.log1p(x_ref) if log1p else x_ref
+        if log1p:
+            assert rel_err(out.cpu().numpy(), ref.numpy()) < 1e-6
+        else:
+            assert np.array_equal(out.cpu().numpy(), ref.numpy())       # raw counts: bit exact
+        assert rel_err(sf.cpu().numpy(), sf_ref.numpy()) < 1e-6
+    # the reference's own collate fixture (tests/golden/host.npz from AnnotatedDataset + custom_collate)
+    rows = np.array([3, 10, 11, 40], dtype=np.int64)
+    out = torch.empty(4, G, device="cuda")
+    sf = torch.empty(4, device="cuda")
+    _lib.check(lib.sca_csr_gather_rows(dev(z["ds_x_indptr"]).data_ptr(), dev(z["ds_x_indices"]).data_ptr(),
+                                       dev(z["ds_x_data"]).data_ptr(), dev(rows).data_ptr(), 4, G, 0, out.data_ptr(), G,
+                                       sf.data_ptr(), st()), "gather")
+    assert np.array_equal(out.cpu().numpy(), z["ds_collate_x"])
+    assert np.allclose(sf.cpu().numpy(), z["ds_collate_sizefactor"])
+
+
+def test_csr_gather_empty_and_ragged(lib):
+    from scarches_amd import _lib
+    # rows with 0 nnz, one very long row, G not a multiple of 4
+    G = 1001
+    indptr = np.array([0, 0, 1001, 1001, 1003], dtype=np.int64)
+    indices = np.concatenate([np.arange(1001), [5, 1000]]).astype(np.int32)
+    data = np.concatenate([np.arange(1, 1002), [7, 9]]).astype(np.float32)
+    out = torch.full((4, G), float("nan"), device="cuda")
+    sf = torch.empty(4, device="cuda")
+    _lib.check(lib.sca_csr_gather_rows(dev(indptr).data_ptr(), dev(indices).data_ptr(), dev(data).data_ptr(), None, 4,
+                                       G, 0, out.data_ptr(), G, sf.data_ptr(), st()), "gather")
+    o = out.cpu().numpy()
+    assert (o[0] == 0).all() and (o[2] == 0).all()
+    assert np.array_equal(o[1], np.arange(1, 1002, dtype=np.float32))
+    assert o[3, 5] == 7 and o[3, 1000] == 9 and o[3].sum() == 16
+    assert np.allclose(sf.cpu().numpy(), [0, data[:1001].sum(), 0, 16])
+
+
+@pytest.mark.parametrize("key", list("abcde"))
+def test_mmd_golden(lib, key):
+    from scarches_amd import _lib
+    from oracle import cvae_oracle as O
+    z = np.load(GOLDEN + "/ops.npz")
+    c = json.loads(str(z[f"mmd_{key}_cfg"]))
+    y, lab = z[f"mmd_{key}_y"], z[f"mmd_{key}_c"]
+    B, D, C = y.shape[0], y.shape[1], c["C"]
+    ns, npart = lib.sca_mmd_num_slabs(B, D), lib.sca_mmd_num_partials(B, D)
+    Wt = torch.empty(C * C, device="cuda")
+    part = torch.zeros(npart, dtype=torch.float64, device="cuda")
+    slabs = torch.full((ns, B, D), float("nan"), device="cuda")
+    _lib.check(lib.sca_mmd_fwd_bwd(dev(y).data_ptr(), D, dev(lab, torch.int32).data_ptr(), B, D, C,
+                                   -1 if c["boundary"] is None else c["boundary"], c["beta"], Wt.data_ptr(), None,
+                                   part.data_ptr(), slabs.data_ptr(), B * D, st()), "mmd")
+    torch.cuda.synchronize()
+    val = part.sum().item()
+    grad = slabs.sum(0).cpu().numpy()
+    ref = float(z[f"mmd_{key}_val"])
+    val64 = O.mmd_loss(torch.tensor(y).double(), torch.tensor(lab), C, c["beta"], c["boundary"]).item()
+    # tolerance: rel 1e-5 of the reference value + the reference's own fp32 cancellation noise (vs the f64 oracle)
+    assert abs(val - ref) <= 1e-5 * abs(ref) + 2 * abs(ref - val64) + 1e-6
+    assert abs(val - val64) <= 1e-5 * abs(val64) + 1e-6
+    if ref != 0:
+        assert rel_err(grad, z[f"mmd_{key}_grad"]) < 5e-5
+
+
+def test_nb_rows_against_oracle(lib):
+    """softmax + NB rows kernel on random logits: per-row ll, dlogits, dtheta, dbias vs the f64 oracle."""
+    from scarches_amd import _lib
+    from oracle import cvae_oracle as O
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    for (B, G, C, zinb) in [(9, 37, 3, 0), (33, 300, 5, 0), (6, 2000, 4, 0), (17, 130, 3, 1), (5, 2500, 2, 0)]:
+        x = rng.poisson(rng.gamma(0.3, 3.0, size=(B, G))).astype(np.float32)
+        x[0, :] = 0
+        if G > 10:
+            x[1, 3] = 3000.0
+        xs = sp.csr_matrix(x)
+        cond = np.sort(rng.integers(0, C, size=B)).astype(np.int32)
+        logits = rng.normal(0, 1.5, size=(B, G)).astype(np.float32)
+        pi = rng.normal(0, 2.0, size=(B, G)).astype(np.float32)
+        theta = rng.normal(0, 1.2, size=(G, C)).astype(np.float32)
+        sf = x.sum(1).astype(np.float32)
+        # oracle (f64)
+        lt = torch.tensor(logits, dtype=torch.float64, requires_grad=True)
+        pt = torch.tensor(pi, dtype=torch.float64, requires_grad=True)
+        tt = torch.tensor(theta, dtype=torch.float64, requires_grad=True)
+        mu = torch.softmax(lt, -1) * torch.tensor(sf, dtype=torch.float64)[:, None]
+        th = torch.exp(tt.T[torch.tensor(cond).long()])
+        xt = torch.tensor(x, dtype=torch.float64)
+        ll = O.zinb_loglik(xt, mu, th, pt) if zinb else O.nb_loglik(xt, mu, th)
+        loss = -ll.sum(-1).mean()
+        loss.backward()
+        # HIP
+        tabt = torch.empty(C, G, device="cuda")
+        tabl = torch.empty(C, G, device="cuda")
+        _lib.check(lib.sca_theta_prep(dev(theta).data_ptr(), G, C, tabt.data_ptr(), tabl.data_ptr(), st()), "prep")
+        ld, pd_ = dev(logits), dev(pi)
+        row_ll = torch.empty(B, device="cuda")
+        dthT = torch.zeros(C, G, device="cuda")
+        db = torch.zeros(G, device="cuda")
+        dbp = torch.zeros(G, device="cuda")
+        for rpb in (1, 4):
+            ld.copy_(torch.tensor(logits)); pd_.copy_(torch.tensor(pi)); dthT.zero_(); db.zero_(); dbp.zero_()
+            _lib.check(lib.sca_recon_rows(zinb, ld.data_ptr(), G, pd_.data_ptr() if zinb else None,
+                                          dev(xs.indptr, torch.int64).data_ptr(), dev(xs.indices, torch.int32).data_ptr(),
+                                          dev(xs.data).data_ptr(), None, dev(sf).data_ptr(), dev(cond).data_ptr(),
+                                          tabt.data_ptr(), tabl.data_ptr(), B, G, C, rpb, row_ll.data_ptr(),
+                                          dthT.data_ptr(), db.data_ptr(), dbp.data_ptr() if zinb else None, 1, st()),
+                       "recon_rows")
+            torch.cuda.synchronize()
+            assert rel_err(row_ll.cpu().numpy(), ll.sum(-1).detach().numpy()) < 2e-6, (B, G, zinb)
+            assert rel_err(ld.cpu().numpy(), lt.grad.numpy()) < 2e-5, (B, G, zinb)
+            assert rel_err((dthT.t() * (-1.0 / B)).cpu().numpy(), tt.grad.numpy()) < 2e-5, (B, G, zinb)
+            assert rel_err(db.cpu().numpy(), lt.grad.sum(0).numpy()) < 2e-5
+            if zinb:
+                assert rel_err(pd_.cpu().numpy(), pt.grad.numpy()) < 2e-5
+                assert rel_err(dbp.cpu().numpy(), pt.grad.sum(0).numpy()) < 2e-5
+
+
+def test_nb_elementwise_golden(lib):
+    """The reference's own nb() values (tests/golden/ops.npz): feed mu directly via logits = log(mu), sf = sum(mu)."""
+    from scarches_amd import _lib
+    import scipy.sparse as sp
+    z = np.load(GOLDEN + "/ops.npz")
+    x, mu, theta = z["nb_x"], z["nb_mu"], z["nb_theta"]
+    B, G = x.shape
+    # theta varies per (b, g) in the fixture: give every row its own "condition"
+    xs = sp.csr_matrix(x)
+    logits = np.log(mu.astype(np.float64))
+    sf = mu.astype(np.float64).sum(1)
+    tabt = dev(theta)                                    # [C=B][G]
+    tabl = dev(np.log(theta.astype(np.float64) + 1e-8).astype(np.float32))
+    ld = dev(logits.astype(np.float32))
+    row_ll = torch.empty(B, device="cuda")
+    dthT = torch.zeros(B, G, device="cuda")
+    _lib.check(lib.sca_recon_rows(0, ld.data_ptr(), G, None, dev(xs.indptr, torch.int64).data_ptr(),
+                                  dev(xs.indices, torch.int32).data_ptr(), dev(xs.data).data_ptr(), None,
+                                  dev(sf.astype(np.float32)).data_ptr(), dev(np.arange(B), torch.int32).data_ptr(),
+                                  tabt.data_ptr(), tabl.data_ptr(), B, G, B, 1, row_ll.data_ptr(), dthT.data_ptr(),
+                                  None, None, 1, st()), "recon_rows")
+    torch.cuda.synchronize()
+    ref = z["nb_ll"].astype(np.float64).sum(1)
+    assert rel_err(row_ll.cpu().numpy(), ref) < 1e-5
+    # theta * dll/dtheta
+    assert rel_err(dthT.cpu().numpy(), theta * z["nb_dtheta"]) < 5e-5
+
+
+def test_adam_kernel(lib):
+    from scarches_amd import _lib
+    from oracle import cvae_oracle as O
+    n = 100003
+    g0 = torch.Generator().manual_seed(1)
+    p = torch.randn(n, generator=g0)
+    pd_, m, v = dev(p.clone()), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    pr, mr, vr = p.clone(), torch.zeros(n), torch.zeros(n)
+    hyper = torch.zeros(8)
+    for t in range(1, 4):
+        g = torch.randn(n, generator=g0) * 0.1
+        hyper[1], hyper[2], hyper[3], hyper[4], hyper[5] = 1e-3, 1 - 0.9 ** t, (1 - 0.999 ** t) ** 0.5, 0.01, 0.0
+        hd = dev(hyper)
+        _lib.check(lib.sca_adam_step(pd_.data_ptr(), dev(g).data_ptr(), m.data_ptr(), v.data_ptr(), n, hd.data_ptr(),
+                                     0.9, 0.999, 0.04, st()), "adam")
+        O.adam_step(pr, g, mr, vr, t, lr=1e-3, eps=0.01, wd=0.04)
+    torch.cuda.synchronize()
+    assert (pd_.cpu() - pr).abs().max().item() < 1e-6
