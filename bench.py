@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""Benchmark of the north-star metric: train cells/sec (fwd + bwd + Adam) of trVAE on 2k HVGs.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): synthetic NB counts, 1M cells x 2000 HVG resident in HBM as CSR, 20 conditions,
+NB loss, MMD on z, hidden [128,128], Z=10, dropout 0.05, Adam(lr 1e-3, eps 0.01, wd 0.04).  One step = one minibatch:
+CSR gather -> forward -> backward -> (gradient all-reduce) -> Adam.  Cells are sharded over ranks (weak scaling:
+--batch cells per GPU per step), no data-path collective except the gradient all-reduce.
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=4096, help="cells per GPU per step")
+    ap.add_argument("--cells", type=int, default=1_000_000, help="total cells over all GPUs")
+    ap.add_argument("--genes", type=int, default=2000)
+    ap.add_argument("--conditions", type=int, default=20)
+    ap.add_argument("--hidden", type=str, default="128,128")
+    ap.add_argument("--latent", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
+    return ap.parse_args()
+
+
+def build_trvae_params(G, C, H, Z, seed=2020):
+    """Random-init weights of the reference architecture, drawn with torch's default nn.Linear init in the
+    reference's module construction order (theta first, then encoder, then decoder)."""
+    from collections import OrderedDict
+    import torch.nn as nn
+    torch.manual_seed(seed)
+    P = OrderedDict()
+    P["theta"] = torch.randn(G, C)
+    sizes = [G] + list(H)
+    for i, (a, b) in enumerate(zip(sizes[:-1], sizes[1:])):
+        if i == 0:
+            e, c = nn.Linear(a, b, bias=True), nn.Linear(C, b, bias=False)
+            P["encoder.FC.L0.expr_L.weight"], P["encoder.FC.L0.expr_L.bias"] = e.weight.data, e.bias.data
+            P["encoder.FC.L0.cond_L.weight"] = c.weight.data
+        else:
+            l = nn.Linear(a, b, bias=True)
+            P[f"encoder.FC.L{i}.weight"], P[f"encoder.FC.L{i}.bias"] = l.weight.data, l.bias.data
+    m, v = nn.Linear(H[-1], Z), nn.Linear(H[-1], Z)
+    P["encoder.mean_encoder.weight"], P["encoder.mean_encoder.bias"] = m.weight.data, m.bias.data
+    P["encoder.log_var_encoder.weight"], P["encoder.log_var_encoder.bias"] = v.weight.data, v.bias.data
+    Hd = list(reversed(H))
+    e, c = nn.Linear(Z, Hd[0], bias=False), nn.Linear(C, Hd[0], bias=False)
+    P["decoder.FirstL.L0.expr_L.weight"], P["decoder.FirstL.L0.cond_L.weight"] = e.weight.data, c.weight.data
+    for i in range(1, len(Hd)):
+        P[f"decoder.HiddenL.L{i}.weight"] = nn.Linear(Hd[i - 1], Hd[i], bias=False).weight.data
+    o = nn.Linear(Hd[-1], G)
+    P["decoder.mean_decoder.0.weight"], P["decoder.mean_decoder.0.bias"] = o.weight.data, o.bias.data
+    return P
+
+
+def epoch_batches(cond_all, n_batches, B, gen):
+    """Stratified sampling with replacement (trainers/trvae/trainer.py:164-170, WeightedRandomSampler with
+    w_i = 1/(N count(cond_i))), one draw for the whole run, cut into batches, each sorted by condition."""
+    counts = torch.bincount(cond_all.long())
+    w = 1.0 / (cond_all.numel() * counts[cond_all.long()].double())
+    ids = torch.multinomial(w, n_batches * B, replacement=True, generator=gen).view(n_batches, B)
+    c = cond_all[ids]
+    order = torch.argsort(c, dim=1, stable=True)
+    return torch.gather(ids, 1, order).contiguous(), torch.gather(c, 1, order).contiguous()
+
+
+def cpu_baseline(P, spec, csr_host, cond_host, B, budget_s=12.0):
+    """The oracle (a torch-CPU restatement of the reference, oracle/cvae_oracle.py) timed on this box's host cores:
+    fwd + autograd bwd + Adam on minibatches of the same workload.  Checker code used as a *baseline only*."""
+    import numpy as np
+    from oracle import cvae_oracle as O
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    indptr, indices, data = csr_host
+    n = len(indptr) - 1
+    rng = np.random.default_rng(0)
+    cfg = dict(spec)
+    Pn = {k: v.clone() for k, v in P.items()}
+    M = {k: torch.zeros_like(v) for k, v in Pn.items()}
+    V = {k: torch.zeros_like(v) for k, v in Pn.items()}
+    done, t0, t = 0, time.time(), 0
+    import scipy.sparse as sp
+    mat = sp.csr_matrix((data, indices, indptr), shape=(n, spec["G"]))
+    while True:
+        rows = np.sort(rng.integers(0, n, size=B))
+        x = torch.tensor(mat[rows].toarray())
+        cond = cond_host[rows]
+        eps = torch.randn(B, spec["Z"])
+        masks = None
+        _, grads, _ = O.trvae_loss_and_grads({k: v.numpy() for k, v in Pn.items()}, cfg, x, cond, x.sum(1), eps, 0.5,
+                                             masks)
+        t += 1
+        for k in Pn:
+            O.adam_step(Pn[k], grads[k], M[k], V[k], t)
+        done += B
+        if time.time() - t0 > budget_s:
+            break
+    dt = time.time() - t0
+    return dict(value=done / dt, unit="cells/s", cores=threads, kind="port",
+                sample=f"{t} steps of B={B} (CSR row slice + fwd + autograd bwd + Adam, dropout off), "
+                       f"{dt:.1f} s on {threads} torch threads")
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    from scarches_amd.engine import CVAEEngine
+    from scarches_amd.synth import make_synthetic_csr
+    from scarches_amd import distributed as sdist
+
+    G, C, Z = a.genes, a.conditions, a.latent
+    H = [int(x) for x in a.hidden.split(",")]
+    B = a.batch
+    n_local = a.cells // world
+    indptr, indices, data, cond_all, _ = make_synthetic_csr(n_local, G, C, dev, seed=1000 + rank)
+    P = build_trvae_params(G, C, H, Z)
+    spec = dict(G=G, C=C, H=H, Z=Z, recon="nb", use_bn=False, use_ln=True, use_mmd=True, mmd_on="z", boundary=None,
+                beta=1.0, dr_rate=0.05, seed=2020 + rank)
+    eng = CVAEEngine(spec, P, dev)
+    eng.bind_csr(indptr, indices, data)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(2020 + rank)
+
+    def run(Bx, steps, warmup):
+        ids, cs = epoch_batches(cond_all, steps + warmup, Bx, gen)
+        def one(i):
+            eng.begin_step(alpha_kl=0.5, lr=1e-3, eps=0.01, clip=0.0)
+            eng.forward_backward(ids[i], cs[i], Bx, train=True, compute_grad=True)
+            if world > 1:
+                sdist.allreduce_mean_(eng.flat_g, world)
+            eng.adam_step(weight_decay=0.04)
+        for i in range(warmup):
+            one(i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(warmup, warmup + steps):
+            one(i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        return dt
+
+    dt = run(B, a.steps, a.warmup)
+    value = B * world * a.steps / dt
+    losses = eng.losses.tolist()
+
+    out = {
+        "metric": "train cells/sec (fwd+bwd+Adam) trVAE 2k-HVG", "value": value, "unit": "cells/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"trVAE synthetic {a.cells} cells x {G} HVG (CSR in HBM, "
+                               f"{data.numel() / n_local:.0f} nnz/cell), {C} conditions, NB loss, MMD on z, hidden {H}, "
+                               f"Z={Z}, dropout 0.05, Adam(eps 0.01, wd 0.04)",
+                   "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}" if world > 1 else "single"},
+        "final_losses": {"recon": losses[0], "kl": losses[1], "mmd": losses[2]},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel family: the fp32 MFMA GEMMs of one step, replayed under HIP events
+        eng.record_gemms = []
+        ids, cs = epoch_batches(cond_all, 1, B, gen)
+        eng.forward_backward(ids[0], cs[0], B)
+        calls = eng.record_gemms
+        eng.record_gemms = None
+        flops = sum(2.0 * c[8] * c[9] * c[10] for c in calls)
+        st = torch.cuda.current_stream(dev)
+        for _ in range(3):
+            eng.replay_gemms(calls)
+        reps = 20
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            eng.replay_gemms(calls)
+        e1.record(st)
+        torch.cuda.synchronize()
+        t_gemm = e0.elapsed_time(e1) * 1e-3 / reps
+        peak = 157.3
+        out["roofline"] = {"bound": "mfma", "achieved": flops / t_gemm / 1e12, "peak": peak, "unit": "TFLOP/s",
+                           "frac": flops / t_gemm / 1e12 / peak, "traffic": None,
+                           "kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32), all GEMM launches of one step",
+                           "launches_per_step": len(calls), "flop_per_step": flops,
+                           "avg_launch_us": t_gemm / len(calls) * 1e6,
+                           "gemm_share_of_step": t_gemm / (dt / a.steps)}
+        if not a.no_sweep and world == 1:
+            sweep = {}
+            for Bx in (128, 1024, 16384):
+                if Bx == B:
+                    continue
+                dts = run(Bx, max(5, a.steps // 2), 3)
+                sweep[str(Bx)] = Bx * max(5, a.steps // 2) / dts
+            out["cells_per_s_by_batch"] = sweep
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(P, spec, (indptr.cpu().numpy(), indices.cpu().numpy(),
+                                                         data.cpu().numpy()), cond_all.cpu().numpy(), min(B, 1024))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

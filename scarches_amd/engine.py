@@ -226,12 +226,25 @@ class CVAEEngine:
         """Launch one GEMM; returns (ptr, S, slab_stride).  S == 1 with `out` writes the final tensor directly."""
         L = self.lib
         S = 1 if force_s1 else L.sca_gemm_splitk_heuristic(M, N, K)
+        rec = getattr(self, "record_gemms", None)
         if S == 1 and out is not None:
-            _lib.check(L.sca_gemm_f32(am, bm, A, lda, Bm, ldb, out, ldc or N, M, N, K, 1, 0, bias, st), "gemm")
+            args = (am, bm, A, lda, Bm, ldb, out, ldc or N, M, N, K, 1, 0, bias)
+            if rec is not None:
+                rec.append(args)
+            _lib.check(L.sca_gemm_f32(*args, st), "gemm")
             return out, 1, 0
         slab = self.ws["slab"].data_ptr()
-        _lib.check(L.sca_gemm_f32(am, bm, A, lda, Bm, ldb, slab, N, M, N, K, S, M * N, None, st), "gemm")
+        args = (am, bm, A, lda, Bm, ldb, slab, N, M, N, K, S, M * N, None)
+        if rec is not None:
+            rec.append(args)
+        _lib.check(L.sca_gemm_f32(*args, st), "gemm")
         return slab, S, M * N
+
+    def replay_gemms(self, calls):
+        """Re-issue recorded GEMM launches (bench.py roofline leg: same shapes, same buffers, nothing else)."""
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        for args in calls:
+            _lib.check(self.lib.sca_gemm_f32(*args, st), "gemm")
 
     def _gemm_to(self, am, bm, A, lda, Bm, ldb, M, N, K, st, dst):
         """GEMM whose (reduced) result lands in the contiguous tensor `dst` [M, N]."""
