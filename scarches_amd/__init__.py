@@ -10,3 +10,6 @@ All arithmetic runs in hand-written HIP kernels (scarches_amd/csrc, C ABI in inc
 fallback: importing works anywhere, using a model needs a gfx950 device and the built libscarches_hip.so.
 """
 __version__ = "0.1.0"
+
+from . import dataset, models, trainers, utils  # noqa: E402,F401
+from .anndata_lite import CellData  # noqa: E402,F401

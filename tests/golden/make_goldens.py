@@ -311,8 +311,8 @@ def surgery_golden(rng):
     adq = FakeAnnData(xq.toarray(), pd.DataFrame({"study": qnames[cq]}))
     torch.manual_seed(12)
     q = quiet(TRVAE.load_query_data, adq, ref)
-    out["q_conditions"] = np.array(q.conditions_)
-    out["q_trainable"] = np.array([n for n, p in q.model.named_parameters() if p.requires_grad])
+    out["q_conditions"] = np.array(q.conditions_).astype(str)
+    out["q_trainable"] = np.array([n for n, p in q.model.named_parameters() if p.requires_grad]).astype(str)
     for k, v in q.model.state_dict().items():
         out["q_w/" + k] = v.detach().numpy().copy()
     out["q_dr_rate"] = np.float32(q.dr_rate_)
@@ -331,7 +331,7 @@ def surgery_golden(rng):
     out.update(q_recon=np.float32(r.item()), q_kl=np.float32(k.item()), q_mmd=np.float32(m.item()),
                q_alpha=np.float32(0.5), q_x_data=xq.data.astype(np.float32), q_x_indices=xq.indices.astype(np.int32),
                q_x_indptr=xq.indptr.astype(np.int64), q_batch=qb.numpy(), q_eps=eps.numpy(),
-               q_study=np.array(adq.obs["study"]), ref_study=np.array(ad.obs["study"]),
+               q_study=np.array(adq.obs["study"]).astype(str), ref_study=np.array(ad.obs["study"]).astype(str),
                cfg=json.dumps(dict(G=G, C=C, H=H, Z=Z)))
     # get_latent through the wrapper (mean=True) on the query cells
     lat = q.get_latent(adq.X, adq.obs["study"], mean=True)
