@@ -42,6 +42,10 @@ int sca_dense_gather_rows(const float* X, int ldX, const int64_t* row_ids, int B
 int sca_gemm_splitk_heuristic(int M, int N, int K);
 int sca_gemm_f32(int amode, int bmode, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
                  int N, int K, int splitk, long long slab_stride, const float* bias, void* stream);
+/* Same with an explicit block tile (64*tile_wm) x (64*tile_wn), tile_w* in {1,2}; 0 = automatic (tuning hook). */
+int sca_gemm_f32_cfg(int amode, int bmode, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
+                     int N, int K, int splitk, long long slab_stride, const float* bias, int tile_wm, int tile_wn,
+                     void* stream);
 int sca_splitk_reduce(const float* slabs, int S, long long slab_stride, float* dst, long long n, void* stream);
 
 /* ---- layer epilogues -----------------------------------------------------------------------------------------

@@ -27,6 +27,7 @@ SIGNATURES = {
     "sca_dense_gather_rows": [P, I, P, I, I, I, P, I, P, P],
     "sca_gemm_splitk_heuristic": [I, I, I],
     "sca_gemm_f32": [I, I, P, I, P, I, P, I, I, I, I, I, LL, P, P],
+    "sca_gemm_f32_cfg": [I, I, P, I, P, I, P, I, I, I, I, I, LL, P, I, I, P],
     "sca_splitk_reduce": [P, I, LL, P, LL, P],
     "sca_layer_fwd": [P, I, LL, I, I, P, P, I, P, P, I, I, I, F, P, U64, U32, P, P, P, P, P],
     "sca_layer_bwd": [P, I, LL, P, I, I, P, P, I, I, F, P, U64, U32, P, P, P],

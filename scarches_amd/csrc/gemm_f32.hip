@@ -24,7 +24,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;
+#ifndef GEMM_OCC
+#define GEMM_OCC 2
+#endif
+#ifndef GEMM_BK
+#define GEMM_BK 16
+#endif
+constexpr int BK = GEMM_BK;
+// block tile = (64*WM) x (64*WN): 2x2 waves, each wave WM x WN MFMA tiles of 32x32.  LDS row stride = rows + 4.
 
 struct GemmArgs {
     const float* A;
@@ -33,22 +40,22 @@ struct GemmArgs {
     const float* bias;   // optional [N], only applied when gridDim.z == 1
     int lda, ldb, ldc;
     int M, N, K;
-    int k_chunk;         // multiple of BK
+    int k_chunk;         // multiple of BK (16)
     long long slab_stride;
     int tiles_m;
 };
 
-// Load one 128(rows) x 16(k) operand tile into two float4 registers per thread.
-template <int MODE, bool VEC>
+// Load one (64*W)(rows) x BK(k) operand tile into W*BK/16 float4 registers per thread.
+template <int MODE, bool VEC, int W>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int R, int r0, int k0, int kend,
-                                          float4 (&reg)[2]) {
+                                          float4 (&reg)[W * BK / 16]) {
     const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < W * BK / 16; ++i) {
         const int idx = t + 256 * i;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (MODE == 0) {
-            const int r = r0 + (idx >> 2), k = k0 + 4 * (idx & 3);
+            const int r = r0 + idx / (BK / 4), k = k0 + 4 * (idx % (BK / 4));
             if (r < R) {
                 const float* p = P + (long long)r * ld + k;
                 if (VEC && k + 3 < kend) {
@@ -61,7 +68,7 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
                 }
             }
         } else {
-            const int k = k0 + (idx >> 5), r = r0 + 4 * (idx & 31);
+            const int k = k0 + idx / (16 * W), r = r0 + 4 * (idx % (16 * W));
             if (k < kend) {
                 const float* p = P + (long long)k * ld + r;
                 if (VEC && r + 3 < R) {
@@ -78,29 +85,31 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
     }
 }
 
-template <int MODE>
-__device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (&reg)[2]) {
+template <int MODE, int W>
+__device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (&reg)[W * BK / 16]) {
+    constexpr int LDT = 64 * W + 4;
     const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < W * BK / 16; ++i) {
         const int idx = t + 256 * i;
         if (MODE == 0) {
-            const int r = idx >> 2, kc = 4 * (idx & 3);
+            const int r = idx / (BK / 4), kc = 4 * (idx % (BK / 4));
             T[(kc + 0) * LDT + r] = reg[i].x;
             T[(kc + 1) * LDT + r] = reg[i].y;
             T[(kc + 2) * LDT + r] = reg[i].z;
             T[(kc + 3) * LDT + r] = reg[i].w;
         } else {
-            const int k = idx >> 5, r = 4 * (idx & 31);
+            const int k = idx / (16 * W), r = 4 * (idx % (16 * W));
             *reinterpret_cast<float4*>(&T[k * LDT + r]) = reg[i];
         }
     }
 }
 
-template <int AMODE, int BMODE, bool VEC>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BK * LDT];
-    constexpr int TSZ = BK * LDT;            // LDS image: [A0 | A1 | B0 | B1]
+template <int AMODE, int BMODE, bool VEC, int WM, int WN>
+__global__ __launch_bounds__(256, GEMM_OCC) void gemm_f32_kernel(const GemmArgs a) {
+    constexpr int BM = 64 * WM, BN = 64 * WN, LDA = BM + 4, LDB = BN + 4;
+    constexpr int ASZ = BK * LDA, BSZ = BK * LDB;            // LDS image: [A0 | A1 | B0 | B1]
+    __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
 
     const int tile = blockIdx.x;
     const int m0 = (tile % a.tiles_m) * BM, n0 = (tile / a.tiles_m) * BN;
@@ -109,43 +118,53 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs a) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wm = w >> 1, wn = w & 1, l31 = lane & 31, half = lane >> 5;
 
-    f32x16 acc[2][2];
+    f32x16 acc[WM][WN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (kend - kbeg + BK - 1) / BK;
-    float4 ra[2], rb[2];
+    float4 ra[WM * BK / 16], rb[WN * BK / 16];
     if (nk > 0) {
-        load_tile<AMODE, VEC>(a.A, a.lda, a.M, m0, kbeg, kend, ra);
-        load_tile<BMODE, VEC>(a.B, a.ldb, a.N, n0, kbeg, kend, rb);
-        store_tile<AMODE>(lds, ra);
-        store_tile<BMODE>(lds + 2 * TSZ, rb);
+        load_tile<AMODE, VEC, WM>(a.A, a.lda, a.M, m0, kbeg, kend, ra);
+        load_tile<BMODE, VEC, WN>(a.B, a.ldb, a.N, n0, kbeg, kend, rb);
+        store_tile<AMODE, WM>(lds, ra);
+        store_tile<BMODE, WN>(lds + 2 * ASZ, rb);
     }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            load_tile<AMODE, VEC>(a.A, a.lda, a.M, m0, kbeg + (kt + 1) * BK, kend, ra);
-            load_tile<BMODE, VEC>(a.B, a.ldb, a.N, n0, kbeg + (kt + 1) * BK, kend, rb);
+            load_tile<AMODE, VEC, WM>(a.A, a.lda, a.M, m0, kbeg + (kt + 1) * BK, kend, ra);
+            load_tile<BMODE, VEC, WN>(a.B, a.ldb, a.N, n0, kbeg + (kt + 1) * BK, kend, rb);
         }
-        const float* Ac = lds + cur * TSZ + half * LDT + wm * 64 + l31;
-        const float* Bc = lds + (2 + cur) * TSZ + half * LDT + wn * 64 + l31;
+        const float* Ac = lds + cur * ASZ + half * LDA + wm * (32 * WM) + l31;
+        const float* Bc = lds + 2 * ASZ + cur * BSZ + half * LDB + wn * (32 * WN) + l31;
+        // all fragment reads of the k-step are issued up front (counted lgkmcnt waits), so the 8*WM*WN MFMAs
+        // run back to back instead of stalling on LDS latency after every k-pair
+        float av[BK / 2][WM], bv[BK / 2][WN];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            const float a0 = Ac[(2 * kk) * LDT], a1 = Ac[(2 * kk) * LDT + 32];
-            const float b0 = Bc[(2 * kk) * LDT], b1 = Bc[(2 * kk) * LDT + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < WM; ++i) av[kk][i] = Ac[(2 * kk) * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bv[kk][j] = Bc[(2 * kk) * LDB + 32 * j];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the reads above: hipcc otherwise sinks them next to each MFMA
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][i], bv[kk][j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nk) {
-            store_tile<AMODE>(lds + (cur ^ 1) * TSZ, ra);
-            store_tile<BMODE>(lds + (2 + (cur ^ 1)) * TSZ, rb);
+            store_tile<AMODE, WM>(lds + (cur ^ 1) * ASZ, ra);
+            store_tile<BMODE, WN>(lds + 2 * ASZ + (cur ^ 1) * BSZ, rb);
         }
         __syncthreads();
     }
@@ -153,31 +172,47 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const GemmArgs a) {
     float* C = a.C + (long long)blockIdx.z * a.slab_stride;
     const bool add_bias = a.bias != nullptr && gridDim.z == 1;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + l31;
+        for (int j = 0; j < WN; ++j) {
+            const int n = n0 + wn * (32 * WN) + j * 32 + l31;
             if (n >= a.N) continue;
             const float bv = add_bias ? a.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int m = m0 + wm * (32 * WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (m < a.M) C[(long long)m * a.ldc + n] = acc[i][j][r] + bv;
             }
         }
 }
 
-// Sum S slabs (+ optional scale) into dst: dst[i] = sum_s slabs[s*stride + i].
+// Sum S slabs into dst: dst[i] = sum_s slabs[s*stride + i].  4 independent accumulation chains keep several
+// slab loads in flight per lane (the slabs are L2/Infinity-Cache resident right after the GEMM).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int S, long long stride,
                                                             float* __restrict__ dst, long long n) {
     const long long i4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i4 >= n) return;
     if (i4 + 3 < n && (stride & 3) == 0) {
-        float4 s = *reinterpret_cast<const float4*>(slabs + i4);
-        for (int k = 1; k < S; ++k) {
-            const float4 v = *reinterpret_cast<const float4*>(slabs + k * stride + i4);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        float4 acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int k = 0;
+        for (; k + 3 < S; k += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 v = *reinterpret_cast<const float4*>(slabs + (k + u) * stride + i4);
+                acc[u].x += v.x; acc[u].y += v.y; acc[u].z += v.z; acc[u].w += v.w;
+            }
         }
+        for (; k < S; ++k) {
+            const float4 v = *reinterpret_cast<const float4*>(slabs + k * stride + i4);
+            acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+        }
+        float4 s;
+        s.x = (acc[0].x + acc[1].x) + (acc[2].x + acc[3].x);
+        s.y = (acc[0].y + acc[1].y) + (acc[2].y + acc[3].y);
+        s.z = (acc[0].z + acc[1].z) + (acc[2].z + acc[3].z);
+        s.w = (acc[0].w + acc[1].w) + (acc[2].w + acc[3].w);
         *reinterpret_cast<float4*>(dst + i4) = s;
     } else {
         for (long long i = i4; i < n && i < i4 + 4; ++i) {
@@ -190,19 +225,50 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" int sca_gemm_splitk_heuristic(int M, int N, int K) {
-    const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+// Tile + split-K plan (measured on MI355X, scripts/gemm_bench*.py): for the skinny shapes of this network
+// (one dimension = 128 or less) 64x64 tiles with the smallest power-of-two split that yields >= 512 workgroups are
+// fastest or tied; 128x128 tiles only pay once the 64x64 grid exceeds ~4096 tiles (large square-ish problems).
+struct GemmPlan { int wm, wn, S; };
+static GemmPlan plan_gemm(int M, int N, int K) {
     const int kt = (K + BK - 1) / BK;
-    int S = 1;
-    // aim for >= 512 workgroups (2 per CU) while keeping >= 4 k-steps per split
-    while (tiles * S < 512 && S * 2 <= 64 && kt / (S * 2) >= 4) S *= 2;
-    return S;
+    const long long t11 = (long long)((M + 63) / 64) * ((N + 63) / 64);
+    GemmPlan p{1, 1, 1};
+    long long tiles = t11;
+    if (t11 >= 4096 && M > 64 && N > 64) {
+        p.wm = p.wn = 2;
+        tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
+    }
+    while (tiles * p.S < 512 && p.S < 64 && kt / (p.S * 2) >= 2) p.S *= 2;
+    return p;
 }
 
-extern "C" int sca_gemm_f32(int amode, int bmode, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
-                            int M, int N, int K, int splitk, long long slab_stride, const float* bias, void* stream) {
+extern "C" int sca_gemm_splitk_heuristic(int M, int N, int K) { return plan_gemm(M, N, K).S; }
+
+template <int AM, int BMD, int WM, int WN>
+static void launch_gemm(const GemmArgs& a, dim3 grid, bool vec, hipStream_t st) {
+    if (vec) hipLaunchKernelGGL((gemm_f32_kernel<AM, BMD, true, WM, WN>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_f32_kernel<AM, BMD, false, WM, WN>), grid, dim3(256), 0, st, a);
+}
+template <int AM, int BMD>
+static void launch_gemm_tile(const GemmArgs& a, int wm, int wn, int tiles_n, int S, bool vec, hipStream_t st) {
+    dim3 grid(a.tiles_m * tiles_n, 1, S);
+    if (wm == 2 && wn == 2) launch_gemm<AM, BMD, 2, 2>(a, grid, vec, st);
+    else if (wm == 1 && wn == 2) launch_gemm<AM, BMD, 1, 2>(a, grid, vec, st);
+    else if (wm == 2 && wn == 1) launch_gemm<AM, BMD, 2, 1>(a, grid, vec, st);
+    else launch_gemm<AM, BMD, 1, 1>(a, grid, vec, st);
+}
+
+// tile_wm / tile_wn in {1,2} select the block tile (64*wm) x (64*wn); 0 = choose automatically.
+extern "C" int sca_gemm_f32_cfg(int amode, int bmode, const float* A, int lda, const float* B, int ldb, float* C,
+                                int ldc, int M, int N, int K, int splitk, long long slab_stride, const float* bias,
+                                int tile_wm, int tile_wn, void* stream) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0 || splitk < 1 || (amode | bmode) & ~1) return -1;
+    if (tile_wm < 0 || tile_wm > 2 || tile_wn < 0 || tile_wn > 2) return -1;
+    if (tile_wm == 0 || tile_wn == 0) {
+        const GemmPlan p = plan_gemm(M, N, K);
+        tile_wm = p.wm; tile_wn = p.wn;
+    }
     GemmArgs a;
     a.A = A; a.B = B; a.C = C; a.bias = bias;
     a.lda = lda; a.ldb = ldb; a.ldc = ldc;
@@ -211,23 +277,24 @@ extern "C" int sca_gemm_f32(int amode, int bmode, const float* A, int lda, const
     const int kt_per = (kt + splitk - 1) / splitk;
     a.k_chunk = kt_per * BK;
     a.slab_stride = slab_stride;
-    a.tiles_m = (M + BM - 1) / BM;
-    const int tiles_n = (N + BN - 1) / BN;
-    dim3 grid(a.tiles_m * tiles_n, 1, splitk), block(256);
+    a.tiles_m = (M + 64 * tile_wm - 1) / (64 * tile_wm);
+    const int tiles_n = (N + 64 * tile_wn - 1) / (64 * tile_wn);
     const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
-#define LAUNCH(AM, BMD)                                                                  \
-    do {                                                                                 \
-        if (vec) hipLaunchKernelGGL((gemm_f32_kernel<AM, BMD, true>), grid, block, 0, st, a);  \
-        else hipLaunchKernelGGL((gemm_f32_kernel<AM, BMD, false>), grid, block, 0, st, a);     \
-    } while (0)
-    if (amode == 0 && bmode == 0) LAUNCH(0, 0);
-    else if (amode == 0 && bmode == 1) LAUNCH(0, 1);
-    else if (amode == 1 && bmode == 1) LAUNCH(1, 1);
-    else LAUNCH(1, 0);
-#undef LAUNCH
+    if (amode == 0 && bmode == 0) launch_gemm_tile<0, 0>(a, tile_wm, tile_wn, tiles_n, splitk, vec, st);
+    else if (amode == 0 && bmode == 1) launch_gemm_tile<0, 1>(a, tile_wm, tile_wn, tiles_n, splitk, vec, st);
+    else if (amode == 1 && bmode == 1) launch_gemm_tile<1, 1>(a, tile_wm, tile_wn, tiles_n, splitk, vec, st);
+    else launch_gemm_tile<1, 0>(a, tile_wm, tile_wn, tiles_n, splitk, vec, st);
     SCA_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int sca_gemm_f32(int amode, int bmode, const float* A, int lda, const float* B, int ldb, float* C, int ldc,
+                            int M, int N, int K, int splitk, long long slab_stride, const float* bias, void* stream) {
+    // tile chosen for the caller's split count (the caller sized its slab workspace from the heuristic)
+    GemmPlan p = plan_gemm(M, N, K);
+    return sca_gemm_f32_cfg(amode, bmode, A, lda, B, ldb, C, ldc, M, N, K, splitk, slab_stride, bias, p.wm, p.wn,
+                            stream);
 }
 
 extern "C" int sca_splitk_reduce(const float* slabs, int S, long long slab_stride, float* dst, long long n,
