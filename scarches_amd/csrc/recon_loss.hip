@@ -59,16 +59,69 @@ struct ReconArgs {
     int compute_grad;
 };
 
+// ---- gamma-function terms of one stored count ---------------------------------------------------------------
+//   lgam = lgamma(x+theta) - lgamma(theta) - lgamma(x+1),   dig = digamma(x+theta) - digamma(theta)
+// Heavy path (any real x > 0): fp64 Stirling series on arguments shifted to >= 8 by the 8-term recurrence; the
+// three shift products collapse into ONE log of their ratio and log(w) is shared between lgamma and digamma.
+struct ShiftD { double w, p, rs; };          // shifted argument, product y(y+1)..(y+7) (1 if unshifted), sum 1/(y+k)
+__device__ __forceinline__ ShiftD shift8(double y, bool want_rs) {
+    ShiftD s{y, 1.0, 0.0};
+    if (y < 8.0) {
+        double num = 0.0, den = 1.0;          // sum_k 1/(y+k) = num/den, built without divisions
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const double f = y + (double)k;
+            num = fma(num, f, den);
+            den *= f;
+        }
+        s.p = den;
+        s.w = y + 8.0;
+        if (want_rs) s.rs = num / den;
+    }
+    return s;
+}
+__device__ __forceinline__ double stirling_lgamma(double w, double lw, double iw) {   // w >= 8
+    const double i2 = iw * iw;
+    const double ser = iw * (1.0 / 12.0 + i2 * (-1.0 / 360.0 + i2 * (1.0 / 1260.0 + i2 * (-1.0 / 1680.0))));
+    return (w - 0.5) * lw - w + 0.91893853320467274178 + ser;
+}
+__device__ __forceinline__ double asym_digamma(double lw, double iw) {                  // w >= 8
+    const double i2 = iw * iw;
+    return lw - 0.5 * iw - i2 * (1.0 / 12.0 - i2 * (1.0 / 120.0 - i2 * (1.0 / 252.0 - i2 * (1.0 / 240.0))));
+}
+__device__ __noinline__ void nb_gamma_terms_heavy(float x, float th, float* lgam, float* dig) {
+    const double xd = (double)x, td = (double)th;
+    const ShiftD a = shift8(xd + td, true), b = shift8(td, true), c = shift8(xd + 1.0, false);
+    const double la = log(a.w), lb = log(b.w), lc = log(c.w);
+    const double ia = 1.0 / a.w, ib = 1.0 / b.w, ic = 1.0 / c.w;
+    const double lg = stirling_lgamma(a.w, la, ia) - stirling_lgamma(b.w, lb, ib) - stirling_lgamma(c.w, lc, ic)
+                      - log(a.p / (b.p * c.p));
+    const double dg = (asym_digamma(la, ia) - a.rs) - (asym_digamma(lb, ib) - b.rs);
+    *lgam = (float)lg;
+    *dig = (float)dg;
+}
+// Fast path: integer count x <= 16 (the bulk of scRNA-seq counts) and moderate theta:
+//   lgam = log prod_{k<x} (theta+k)/(k+1),  dig = sum_{k<x} 1/(theta+k)   (exact identities, fp32, no cancellation)
+__device__ __forceinline__ bool nb_gamma_fast_ok(float x, float th) {
+    return x <= 16.0f && x == floorf(x) && th < 128.0f && th > 1e-30f;
+}
+
+constexpr int QMAX = 1024;     // LDS queue of heavy entries per row (overflow is handled inline)
+
 template <int T, int EPT, bool ZINB>
 __global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* tx = lds;              // [G] per-row extras of t = mu dll/dmu at nnz (cleared by the owner when read)
     float* dx = lds + a.G;        // [G] theta-gradient extras, accumulated over the rows of a condition run
     float* px = lds + 2 * a.G;    // [G] ZINB: dpi extras (cleared when read)
-    __shared__ float red[16];
-    const int G = a.G, t = threadIdx.x;
+    __shared__ float red[2][2][16];
+    __shared__ int queue[QMAX];
+    __shared__ int qn;
+    const int G = a.G, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    constexpr int NW = T / 64;
     const int nlds = (ZINB ? 3 : 2) * G;
     for (int i = t; i < nlds; i += T) lds[i] = 0.f;
+    if (t == 0) qn = 0;
 
     float acc_th[EPT], acc_b[EPT], acc_p[EPT];
 #pragma unroll
@@ -76,6 +129,7 @@ __global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
 
     const int b0 = blockIdx.x * a.rows_per_block, b1 = min(a.B, b0 + a.rows_per_block);
     const float invB = 1.0f / (float)a.B;
+    int par = 0;                  // reduction scratch parity: alternating buffers need ONE barrier per reduction
     for (int b = b0; b < b1; ++b) {
         const int c = a.cond ? a.cond[b] : 0;
         const float s = a.sizefactor[b];
@@ -84,6 +138,7 @@ __global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
         const float* tth = a.tab_theta + (long long)c * G;
         const float* tlt = a.tab_lte + (long long)c * G;
 
+        // ---- online softmax statistics: per-thread (max, sum exp), merged across the workgroup in one round
         float lg[EPT];
         float mx = -INFINITY;
 #pragma unroll
@@ -92,18 +147,28 @@ __global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
             lg[j] = g < G ? lrow[g] : -INFINITY;
             mx = fmaxf(mx, lg[j]);
         }
-        mx = block_max(mx, red);
         float se = 0.f;
 #pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-            lg[j] = (t + T * j < G) ? expf(lg[j] - mx) : 0.f;      // lg now holds exp(l - max)
-            se += lg[j];
+        for (int j = 0; j < EPT; ++j) se += (t + T * j < G) ? __expf(lg[j] - mx) : 0.f;
+        {
+            float wm = wave_max(mx);
+            se *= (mx == -INFINITY) ? 0.f : __expf(mx - wm);
+            se = wave_sum(se);
+            if (lane == 0) { red[par][0][wv] = wm; red[par][1][wv] = se; }
+            __syncthreads();
+            float M = red[par][0][0];
+#pragma unroll
+            for (int i = 1; i < NW; ++i) M = fmaxf(M, red[par][0][i]);
+            float S = 0.f;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) S += red[par][1][i] * __expf(red[par][0][i] - M);
+            mx = M; se = S;
+            par ^= 1;
         }
-        se = block_sum(se, red);
         const float inv = 1.0f / se;
 
         // ---- sparse phase: one lane per stored count of this row
-        float ll = 0.f, Tsum = 0.f;
+        float ll = 0.f;
         const int64_t r = a.row_ids ? a.row_ids[b] : (int64_t)b;
         const int64_t ks = a.indptr[r], ke = a.indptr[r + 1];
         for (int64_t k = ks + t; k < ke; k += T) {
@@ -111,15 +176,27 @@ __global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
             if (!(x > NB_EPS)) continue;
             const int g = a.indices[k];
             const float th = tth[g];
-            const float mu = expf(lrow[g] - mx) * inv * s;
+            const float mu = __expf(lrow[g] - mx) * inv * s;
             const float den = th + mu + NB_EPS;
-            const float L = logf(den), rr = 1.0f / den;
-            const double xd = (double)x, thd = (double)th;
-            const double lgam = lgamma(xd + thd) - lgamma(thd) - lgamma(xd + 1.0);
-            const double dig = digamma_pos(xd + thd) - digamma_pos(thd);
-            float ex_ll = x * (logf(mu + NB_EPS) - L) + (float)lgam;
-            float ex_t = mu * (x / (mu + NB_EPS) - x * rr);
-            float ex_th = th * (-x * rr + (float)dig);
+            const float L = __logf(den), rr = __builtin_amdgcn_rcpf(den);
+            float lgam = 0.f, dig = 0.f;
+            if (nb_gamma_fast_ok(x, th)) {
+                const int n = min((int)x, 16);
+                float P = 1.f;
+                for (int q = 0; q < n; ++q) {
+                    const float f = th + (float)q;
+                    P *= f * __builtin_amdgcn_rcpf((float)(q + 1));
+                    dig += __builtin_amdgcn_rcpf(f);
+                }
+                lgam = __logf(P);
+            } else {
+                const int slot = atomicAdd(&qn, 1);
+                if (slot < QMAX) queue[slot] = (int)(k - ks);
+                else nb_gamma_terms_heavy(x, th, &lgam, &dig);
+            }
+            float ex_ll = x * (__logf(mu + NB_EPS) - L) + lgam;
+            float ex_t = mu * x * (__builtin_amdgcn_rcpf(mu + NB_EPS) - rr);
+            float ex_th = th * (-x * rr + dig);
             if (ZINB) {
                 // replace the zero-case (evaluated for every gene in the dense sweep) by the non-zero case
                 const float pv = prow[g];
@@ -137,8 +214,23 @@ __global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
             dx[g] += ex_th;
         }
         __syncthreads();
+        // ---- heavy entries (large / non-integer counts), compacted so the fp64 code runs on full lanes
+        {
+            const int nq = min(qn, QMAX);
+            for (int q = t; q < nq; q += T) {
+                const int64_t k = ks + queue[q];
+                const float x = a.data[k];
+                const int g = a.indices[k];
+                const float th = tth[g];
+                float lgam, dig;
+                nb_gamma_terms_heavy(x, th, &lgam, &dig);
+                ll += lgam;
+                dx[g] += th * dig;        // one entry per gene per row: no other lane touches dx[g] in this phase
+            }
+        }
 
         // ---- dense sweep (x = 0 terms for every gene)
+        float Tsum = 0.f;
         float tj[EPT], pj[EPT];
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
@@ -146,12 +238,12 @@ __global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
             tj[j] = 0.f; pj[j] = 0.f;
             if (g < G) {
                 const float th = tth[g], lte = tlt[g];
-                const float gam = lg[j] * inv;
+                const float gam = __expf(lg[j] - mx) * inv;
                 const float mu = gam * s;
                 const float den = th + mu + NB_EPS;
-                const float L = logf(den), rr = 1.0f / den;
+                const float L = __logf(den), rr = __builtin_amdgcn_rcpf(den);
                 const float base = th * (lte - L);
-                const float dbase_dth = lte - L + th / (th + NB_EPS) - th * rr;
+                const float dbase_dth = lte - L + th * (__builtin_amdgcn_rcpf(th + NB_EPS) - rr);
                 float tv, dth;
                 if (ZINB) {
                     const float pv = prow[g];
@@ -175,9 +267,17 @@ __global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
                 lg[j] = gam;                                          // lg now holds gamma
             }
         }
-        ll = block_sum(ll, red);
-        Tsum = block_sum(Tsum, red);
-        if (t == 0) a.row_ll[b] = ll;
+        {
+            ll = wave_sum(ll);
+            Tsum = wave_sum(Tsum);
+            if (lane == 0) { red[par][0][wv] = ll; red[par][1][wv] = Tsum; }
+            __syncthreads();                  // also orders the queue / tx / dx traffic of this row before the next
+            ll = 0.f; Tsum = 0.f;
+#pragma unroll
+            for (int i = 0; i < NW; ++i) { ll += red[par][0][i]; Tsum += red[par][1][i]; }
+            par ^= 1;
+        }
+        if (t == 0) { a.row_ll[b] = ll; qn = 0; }
 
         if (a.compute_grad) {
 #pragma unroll
