@@ -135,6 +135,11 @@ class CVAEEngine:
         self.accum = torch.zeros(5, dtype=torch.float64, device=dev)
         self.csr = None
         self.Bcap = 0
+        # side stream: MMD runs beside the decoder, every dW / bias / condition-weight gradient beside the dX chain
+        self.aux = torch.cuda.Stream(device=self.device)
+        self._events = [torch.cuda.Event() for _ in range(32)]
+        self._ev_i = 0
+        self.overlap = True
         self.set_hyper(alpha_kl=1.0, lr=1e-3, eps=0.01, clip=0.0)
 
     # ------------------------------------------------------------------------------------------ configuration
@@ -211,6 +216,9 @@ class CVAEEngine:
         for (M, N, K) in shapes:
             need = max(need, L.sca_gemm_splitk_heuristic(M, N, K) * M * N)
         ws["slab"] = torch.empty(need, dtype=f32, device=dev)
+        ws["slab_aux"] = torch.empty(need, dtype=f32, device=dev)
+        for ly in self.enc + self.dec:
+            ws[ly.tag + ".da"] = torch.empty(B, ly.n_out, dtype=f32, device=dev)
         Dm = Z if self.mmd_on == "z" else self.dec[0].n_out
         self._mmd_ns = L.sca_mmd_num_slabs(B, Dm)
         ws["mmd_g"] = torch.empty(max(1, self._mmd_ns) * B * Dm, dtype=f32, device=dev)
@@ -222,7 +230,27 @@ class CVAEEngine:
         self.Bcap = B
 
     # ------------------------------------------------------------------------------------------ helpers
-    def _gemm(self, am, bm, A, lda, Bm, ldb, M, N, K, st, out=None, ldc=None, bias=None, force_s1=False):
+    def _fork(self):
+        """aux stream waits for everything enqueued on the main stream so far."""
+        if not self.overlap:
+            return torch.cuda.current_stream(self.device).cuda_stream
+        ev = self._events[self._ev_i]
+        self._ev_i = (self._ev_i + 1) % len(self._events)
+        ev.record(torch.cuda.current_stream(self.device))
+        self.aux.wait_event(ev)
+        return self.aux.cuda_stream
+
+    def _join(self):
+        """main stream waits for everything enqueued on the aux stream so far."""
+        if not self.overlap:
+            return
+        ev = self._events[self._ev_i]
+        self._ev_i = (self._ev_i + 1) % len(self._events)
+        ev.record(self.aux)
+        torch.cuda.current_stream(self.device).wait_event(ev)
+
+    def _gemm(self, am, bm, A, lda, Bm, ldb, M, N, K, st, out=None, ldc=None, bias=None, force_s1=False,
+              slab_key="slab"):
         """Launch one GEMM; returns (ptr, S, slab_stride).  S == 1 with `out` writes the final tensor directly."""
         L = self.lib
         S = 1 if force_s1 else L.sca_gemm_splitk_heuristic(M, N, K)
@@ -233,7 +261,7 @@ class CVAEEngine:
                 rec.append(args)
             _lib.check(L.sca_gemm_f32(*args, st), "gemm")
             return out, 1, 0
-        slab = self.ws["slab"].data_ptr()
+        slab = self.ws[slab_key].data_ptr()
         args = (am, bm, A, lda, Bm, ldb, slab, N, M, N, K, S, M * N, None)
         if rec is not None:
             rec.append(args)
@@ -246,10 +274,10 @@ class CVAEEngine:
         for args in calls:
             _lib.check(self.lib.sca_gemm_f32(*args, st), "gemm")
 
-    def _gemm_to(self, am, bm, A, lda, Bm, ldb, M, N, K, st, dst):
+    def _gemm_to(self, am, bm, A, lda, Bm, ldb, M, N, K, st, dst, slab_key="slab"):
         """GEMM whose (reduced) result lands in the contiguous tensor `dst` [M, N]."""
         L = self.lib
-        p, S, stride = self._gemm(am, bm, A, lda, Bm, ldb, M, N, K, st, out=dst.data_ptr(), ldc=N)
+        p, S, stride = self._gemm(am, bm, A, lda, Bm, ldb, M, N, K, st, out=dst.data_ptr(), ldc=N, slab_key=slab_key)
         if p != dst.data_ptr():
             _lib.check(L.sca_splitk_reduce(p, S, stride, dst.data_ptr(), M * N, st), "splitk_reduce")
 
@@ -301,10 +329,28 @@ class CVAEEngine:
         _lib.check(L.sca_latent_fwd(sp, S, stride, self.heads_b.data_ptr(), B, Z, ptr(eps), self.seed, 1, step_p, 1,
                                     ws["mu_lv"].data_ptr(), ws["eps"].data_ptr(), ws["z"].data_ptr(),
                                     ws["kl_row"].data_ptr(), st), "latent_fwd")
+        # MMD (value + gradient w.r.t. z or y1) runs on the aux stream beside the decoder / reconstruction kernels
+        n_part = 0
+
+        def launch_mmd():
+            feat, Dm = (ws["z"], Z) if self.mmd_on == "z" else (ws["dec0.h"], self.dec[0].n_out)
+            sa = self._fork()
+            _lib.check(L.sca_mmd_fwd_bwd(feat.data_ptr(), Dm, cond_p, B, Dm, C,
+                                         -1 if self.boundary is None else int(self.boundary), self.beta,
+                                         ws["Wt"].data_ptr(), ws["counts"].data_ptr(), ws["mmd_part"].data_ptr(),
+                                         ws["mmd_g"].data_ptr() if compute_grad else None, B * Dm, sa), "mmd")
+            self._mmd_ns_cur = L.sca_mmd_num_slabs(B, Dm)
+            return L.sca_mmd_num_partials(B, Dm)
+
+        do_mmd = self.use_mmd and C > 0
+        if do_mmd and self.mmd_on == "z":
+            n_part = launch_mmd()
         # 4. decoder
         a = ws["z"].data_ptr()
-        for ly in self.dec:
+        for i, ly in enumerate(self.dec):
             a = layer_forward(ly, a)
+            if i == 0 and do_mmd and self.mmd_on != "z":
+                n_part = launch_mmd()
         Hd = self.dec[-1].n_out
         # 5. output layer + reconstruction loss (+ gradient w.r.t. the logits, in place)
         self._gemm(0, 0, a, Hd, P[self.out_w].data_ptr(), Hd, B, G, Hd, st, out=ws["logits"].data_ptr(), ldc=G,
@@ -340,17 +386,8 @@ class CVAEEngine:
                                         if zinb and self.trainable["decoder.dropout_decoder.bias"] else None,
                                         int(compute_grad), st), "recon_rows")
             recon_sign = -1.0
-        # 6. MMD (value + gradient w.r.t. z or y1)
-        n_part = 0
-        if self.use_mmd and C > 0:
-            feat, Dm = (ws["z"], Z) if self.mmd_on == "z" else (ws["dec0.h"], self.dec[0].n_out)
-            ns = L.sca_mmd_num_slabs(B, Dm)
-            n_part = L.sca_mmd_num_partials(B, Dm)
-            _lib.check(L.sca_mmd_fwd_bwd(feat.data_ptr(), Dm, cond_p, B, Dm, C,
-                                         -1 if self.boundary is None else int(self.boundary), self.beta,
-                                         ws["Wt"].data_ptr(), ws["counts"].data_ptr(), ws["mmd_part"].data_ptr(),
-                                         ws["mmd_g"].data_ptr() if compute_grad else None, B * Dm, st), "mmd")
-            self._mmd_ns_cur = ns
+        if n_part:
+            self._join()          # MMD value (and gradient slabs) are ready
         _lib.check(L.sca_finalize_losses(ws["row_ll"].data_ptr(), recon_sign, ws["kl_row"].data_ptr(), B,
                                          ws["mmd_part"].data_ptr(), n_part, self.hyper.data_ptr(),
                                          self.losses.data_ptr(), self.accum.data_ptr() if accumulate_logs else None,
@@ -361,34 +398,61 @@ class CVAEEngine:
         return self.losses
 
     def _backward(self, B, cond_p, p_drop, masks, st, have_mmd):
+        """Backward pass.  The dX chain (layer_bwd -> dX GEMM -> ...) is the critical path and stays on the main
+        stream; every weight / bias / condition-weight gradient only feeds Adam, so it is issued on the aux stream
+        (own slab workspace, per-layer `da` buffers) and joined once at the end."""
         L, P, Gd, ws, T = self.lib, self.p, self.g, self.ws, self.trainable
         G, C, Z = self.G, self.C, self.Z
         ptr = _lib.ptr
         step_p = self.step_ctr.data_ptr()
-        # theta gradient: -1/B * sum_b theta dll/dtheta, transposed back to the [G][C] parameter layout
-        if self.recon != "mse" and T["theta"]:
-            _lib.check(L.sca_transpose_scale(ws["dthetaT"].data_ptr(), max(C, 1), G, -1.0 / B,
-                                             Gd["theta"].data_ptr(), st), "transpose_scale")
-        # output layer(s)
+        AUX = "slab_aux" if self.overlap else "slab"
         Hd = self.dec[-1].n_out
         h_last = ws[self.dec[-1].tag + ".h"].data_ptr()
         dl = ws["logits"].data_ptr()
+
+        # ---- side work that depends only on the reconstruction kernel's outputs
+        sa = self._fork()
+        if self.recon != "mse" and T["theta"]:
+            # theta gradient: -1/B * sum_b theta dll/dtheta, transposed back to the [G][C] parameter layout
+            _lib.check(L.sca_transpose_scale(ws["dthetaT"].data_ptr(), max(C, 1), G, -1.0 / B,
+                                             Gd["theta"].data_ptr(), sa), "transpose_scale")
         if T[self.out_w]:
-            self._gemm_to(1, 1, dl, G, h_last, Hd, G, Hd, B, st, Gd[self.out_w])
-        # dX of the output layer (+ the ZINB dropout head, which shares the input): slabs feed the next layer_bwd
+            self._gemm_to(1, 1, dl, G, h_last, Hd, G, Hd, B, sa, Gd[self.out_w], slab_key=AUX)
+        extra = None
         if self.recon == "zinb":
             dp = ws["pi"].data_ptr()
             if T["decoder.dropout_decoder.weight"]:
-                self._gemm_to(1, 1, dp, G, h_last, Hd, G, Hd, B, st, Gd["decoder.dropout_decoder.weight"])
+                self._gemm_to(1, 1, dp, G, h_last, Hd, G, Hd, B, sa, Gd["decoder.dropout_decoder.weight"],
+                              slab_key=AUX)
             # dh = dl @ Wo + dpi @ Wp : the second product is reduced into a scratch [B, Hd] and joins as `extra`
             scratch = self._scratch_bh(B, Hd)
             self._gemm_to(0, 1, dp, G, P["decoder.dropout_decoder.weight"].data_ptr(), Hd, B, Hd, G, st, scratch)
             extra = scratch.data_ptr()
-        else:
-            extra = None
         sp, S, stride = self._gemm(0, 1, dl, G, P[self.out_w].data_ptr(), Hd, B, Hd, G, st)
 
-        # decoder, last -> first
+        def layer_backward(ly, a_prev, sp, S, stride, extra, need_dx):
+            m = masks.get(ly.mask_key)
+            da = ws[ly.tag + ".da"].data_ptr()
+            _lib.check(L.sca_layer_bwd(sp, S, stride, extra, B, ly.n_out, ws[ly.tag + ".yn"].data_ptr(),
+                                       ws[ly.tag + ".rs"].data_ptr(), self.norm, 1, p_drop, ptr(m), self.seed,
+                                       ly.rng_stream, step_p, da, st), "layer_bwd")
+            need_w = T[ly.w]
+            need_b = bool(ly.b) and T[ly.b]
+            need_c = bool(ly.wc) and T[ly.wc]
+            if need_w or need_b or need_c:
+                sa = self._fork()
+                if need_w:
+                    self._gemm_to(1, 1, da, ly.n_out, a_prev, ly.n_in, ly.n_out, ly.n_in, B, sa, Gd[ly.w],
+                                  slab_key=AUX)
+                if need_b or need_c:
+                    _lib.check(L.sca_cond_colsum(da, B, ly.n_out, cond_p if ly.wc else None, C if ly.wc else 0,
+                                                 ws["segT"].data_ptr(), Gd[ly.wc].data_ptr() if need_c else None,
+                                                 Gd[ly.b].data_ptr() if need_b else None, sa), "cond_colsum")
+            if need_dx:
+                return self._gemm(0, 1, da, ly.n_out, P[ly.w].data_ptr(), ly.n_in, B, ly.n_in, ly.n_out, st)
+            return None, 0, 0
+
+        # ---- decoder, last -> first
         for li in range(len(self.dec) - 1, -1, -1):
             ly = self.dec[li]
             if li == 0 and have_mmd and self.mmd_on == "y":
@@ -398,21 +462,11 @@ class CVAEEngine:
                 if extra is not None:       # single-hidden-layer ZINB net: both extras land on the same layer
                     ws["mmd_extra"].view(-1)[:B * ly.n_out].add_(self._scratch_bh(B, ly.n_out).view(-1))
                 extra = ws["mmd_extra"].data_ptr()
-            m = masks.get(ly.mask_key)
-            da = ws["da"].data_ptr()
-            _lib.check(L.sca_layer_bwd(sp, S, stride, extra, B, ly.n_out, ws[ly.tag + ".yn"].data_ptr(),
-                                       ws[ly.tag + ".rs"].data_ptr(), self.norm, 1, p_drop, ptr(m), self.seed,
-                                       ly.rng_stream, step_p, da, st), "layer_bwd")
-            extra = None
             a_prev = ws["z"].data_ptr() if li == 0 else ws[self.dec[li - 1].tag + ".h"].data_ptr()
-            if T[ly.w]:
-                self._gemm_to(1, 1, da, ly.n_out, a_prev, ly.n_in, ly.n_out, ly.n_in, B, st, Gd[ly.w])
-            if ly.wc and T[ly.wc]:
-                _lib.check(L.sca_cond_colsum(da, B, ly.n_out, cond_p, C, ws["segT"].data_ptr(),
-                                             Gd[ly.wc].data_ptr(), None, st), "cond_colsum")
-            sp, S, stride = self._gemm(0, 1, da, ly.n_out, P[ly.w].data_ptr(), ly.n_in, B, ly.n_in, ly.n_out, st)
+            sp, S, stride = layer_backward(ly, a_prev, sp, S, stride, extra, True)
+            extra = None
 
-        # latent block: dz (decoder) + dz (MMD on z) + KL
+        # ---- latent block: dz (decoder) + dz (MMD on z) + KL
         use_mz = have_mmd and self.mmd_on == "z"
         _lib.check(L.sca_latent_bwd(sp, S, stride, ws["mmd_g"].data_ptr() if use_mz else None,
                                     self._mmd_ns_cur if use_mz else 0, B * Z, ws["mu_lv"].data_ptr(),
@@ -421,32 +475,19 @@ class CVAEEngine:
         Hl = self.H[-1]
         h_enc = ws[self.enc[-1].tag + ".h"].data_ptr()
         dh = ws["dheads"].data_ptr()
-        heads_train = T["encoder.mean_encoder.weight"]
-        if heads_train:
-            self._gemm_to(1, 1, dh, 2 * Z, h_enc, Hl, 2 * Z, Hl, B, st, self.heads_gw)
+        if T["encoder.mean_encoder.weight"]:
+            sa = self._fork()
+            self._gemm_to(1, 1, dh, 2 * Z, h_enc, Hl, 2 * Z, Hl, B, sa, self.heads_gw, slab_key=AUX)
             _lib.check(L.sca_cond_colsum(dh, B, 2 * Z, None, 0, ws["segT"].data_ptr(), None,
-                                         self.heads_gb.data_ptr(), st), "heads_bias")
+                                         self.heads_gb.data_ptr(), sa), "heads_bias")
         sp, S, stride = self._gemm(0, 1, dh, 2 * Z, self.heads_w.data_ptr(), Hl, B, Hl, 2 * Z, st)
 
-        # encoder, last -> first
+        # ---- encoder, last -> first
         for li in range(len(self.enc) - 1, -1, -1):
             ly = self.enc[li]
-            m = masks.get(ly.mask_key)
-            da = ws["da"].data_ptr()
-            _lib.check(L.sca_layer_bwd(sp, S, stride, None, B, ly.n_out, ws[ly.tag + ".yn"].data_ptr(),
-                                       ws[ly.tag + ".rs"].data_ptr(), self.norm, 1, p_drop, ptr(m), self.seed,
-                                       ly.rng_stream, step_p, da, st), "layer_bwd")
             a_prev = ws["x"].data_ptr() if li == 0 else ws[self.enc[li - 1].tag + ".h"].data_ptr()
-            if T[ly.w]:
-                self._gemm_to(1, 1, da, ly.n_out, a_prev, ly.n_in, ly.n_out, ly.n_in, B, st, Gd[ly.w])
-            need_b = ly.b and T[ly.b]
-            need_c = ly.wc and T[ly.wc]
-            if need_b or need_c:
-                _lib.check(L.sca_cond_colsum(da, B, ly.n_out, cond_p if ly.wc else None, C if ly.wc else 0,
-                                             ws["segT"].data_ptr(), Gd[ly.wc].data_ptr() if need_c else None,
-                                             Gd[ly.b].data_ptr() if need_b else None, st), "cond_colsum")
-            if li > 0:
-                sp, S, stride = self._gemm(0, 1, da, ly.n_out, P[ly.w].data_ptr(), ly.n_in, B, ly.n_in, ly.n_out, st)
+            sp, S, stride = layer_backward(ly, a_prev, sp, S, stride, None, li > 0)
+        self._join()
 
     def _scratch_bh(self, B, Hd):
         if not hasattr(self, "_sbh") or self._sbh.numel() < B * Hd:
