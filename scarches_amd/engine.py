@@ -224,6 +224,7 @@ class CVAEEngine:
         ws["mmd_g"] = torch.empty(max(1, self._mmd_ns) * B * Dm, dtype=f32, device=dev)
         ws["mmd_part"] = torch.zeros(max(1, L.sca_mmd_num_partials(B, Dm)), dtype=torch.float64, device=dev)
         ws["mmd_extra"] = torch.empty(B, Dm, dtype=f32, device=dev)
+        self._sbh = torch.empty(B * Hmax, dtype=f32, device=dev)
         ws["Wt"] = torch.empty(C * C, dtype=f32, device=dev)
         ws["counts"] = torch.empty(C, dtype=torch.int32, device=dev)
         self.ws = ws
@@ -355,8 +356,8 @@ class CVAEEngine:
         # 5. output layer + reconstruction loss (+ gradient w.r.t. the logits, in place)
         self._gemm(0, 0, a, Hd, P[self.out_w].data_ptr(), Hd, B, G, Hd, st, out=ws["logits"].data_ptr(), ldc=G,
                    bias=P[self.out_b].data_ptr(), force_s1=True)
-        if compute_grad:
-            self.flat_g.zero_()
+        if compute_grad and self.trainable[self.out_b]:
+            self.g[self.out_b].zero_()          # accumulated by atomics; every other gradient is overwritten
         rpb = max(1, B // 1024)
         if self.recon == "mse":
             _lib.check(L.sca_mse_rows(ws["logits"].data_ptr(), G, ws["x"].data_ptr(), G, B, G, rpb,
@@ -527,6 +528,68 @@ class CVAEEngine:
             _lib.check(L.sca_adam_step(self.flat_p[s:].data_ptr(), self.flat_g[s:].data_ptr(),
                                        self.flat_m[s:].data_ptr(), self.flat_v[s:].data_ptr(), e - s,
                                        self.hyper.data_ptr(), 0.9, 0.999, weight_decay, st), "adam")
+
+    # ------------------------------------------------------------------------------------------ HIP-graph step
+    def train_step(self, row_ids, cond, B, alpha_kl, lr, eps=0.01, clip=0.0, weight_decay=0.04, world=1,
+                   use_graph=True):
+        """One optimisation step: forward + backward (+ gradient all-reduce) + Adam.
+
+        With use_graph the launch sequence of this batch size is captured once into HIP graphs (all per-step
+        scalars live in device memory: `hyper`, `step_ctr`; minibatch ids are copied into static buffers) and
+        replayed: ~60 kernel launches cost one graph launch on the host."""
+        self.begin_step(alpha_kl, lr, eps, clip)
+        if not use_graph:
+            self.forward_backward(row_ids, cond, B)
+            if world > 1:
+                from . import distributed as sdist
+                sdist.allreduce_mean_(self.flat_g, world)
+            self.adam_step(weight_decay)
+            return self.losses
+        key = (B, float(weight_decay), world > 1, tuple(sorted(k for k, v in self.trainable.items() if v)),
+               self.use_mmd, self.mmd_on, self.boundary, self.beta)
+        g = self._graphs.get(key) if hasattr(self, "_graphs") else None
+        if g is None:
+            g = self._capture(B, weight_decay, world > 1, key)
+        g["rows"].copy_(row_ids, non_blocking=True)
+        g["cond"].copy_(cond, non_blocking=True)
+        g["fwd"].replay()
+        if world > 1:
+            from . import distributed as sdist
+            sdist.allreduce_mean_(self.flat_g, world)
+            g["adam"].replay()
+        return self.losses
+
+    def _capture(self, B, weight_decay, split, key):
+        if not hasattr(self, "_graphs"):
+            self._graphs = {}
+        self._ensure(B)
+        rows = torch.zeros(B, dtype=torch.int64, device=self.device)
+        cond = torch.zeros(B, dtype=torch.int32, device=self.device)
+        # warm-up on a side stream (workspaces, lazy module loads), leaving parameters / Adam state untouched
+        snap = (self.flat_p.clone(), self.flat_m.clone(), self.flat_v.clone(), self.accum.clone())
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            self.forward_backward(rows, cond, B)
+            self.adam_step(weight_decay)
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        out = dict(rows=rows, cond=cond)
+        gf = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gf):
+            self.forward_backward(rows, cond, B)
+            if not split:
+                self.adam_step(weight_decay)
+        out["fwd"] = gf
+        if split:
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                self.adam_step(weight_decay)
+            out["adam"] = ga
+        torch.cuda.synchronize(self.device)
+        self.flat_p.copy_(snap[0]); self.flat_m.copy_(snap[1]); self.flat_v.copy_(snap[2]); self.accum.copy_(snap[3])
+        self._graphs[key] = out
+        return out
 
     def begin_step(self, alpha_kl, lr, eps=0.01, clip=0.0):
         self.adam_t += 1

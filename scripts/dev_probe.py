@@ -39,3 +39,12 @@ for B in (128, 1024, 4096, 16384):
     torch.cuda.synchronize()
     dt = (time.time() - t0) / K
     print(f'B={B} eager {dt*1e3:.3f} ms/step  {B/dt/1e6:.3f} Mcells/s  losses', eng.losses.tolist())
+    for it in range(3):
+        eng.train_step(ids, c, B, 0.5, 1e-3)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for it in range(K):
+        eng.train_step(ids, c, B, 0.5, 1e-3)
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / K
+    print(f'B={B} graph {dt*1e3:.3f} ms/step  {B/dt/1e6:.3f} Mcells/s  losses', eng.losses.tolist())
