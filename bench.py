@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--latent", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
+                    help="HIP-graph replay, eager launches, or auto (graphs for B <= 2048)")
     return ap.parse_args()
 
 
@@ -147,11 +149,9 @@ def main():
     def run(Bx, steps, warmup):
         ids, cs = epoch_batches(cond_all, steps + warmup, Bx, gen)
         def one(i):
-            eng.begin_step(alpha_kl=0.5, lr=1e-3, eps=0.01, clip=0.0)
-            eng.forward_backward(ids[i], cs[i], Bx, train=True, compute_grad=True)
-            if world > 1:
-                sdist.allreduce_mean_(eng.flat_g, world)
-            eng.adam_step(weight_decay=0.04)
+            # gather -> fwd -> bwd -> (RCCL gradient all-reduce) -> Adam; see --launch
+            eng.train_step(ids[i], cs[i], Bx, alpha_kl=0.5, lr=1e-3, eps=0.01, clip=0.0, weight_decay=0.04,
+                           world=world, use_graph={"auto": "auto", "graph": True, "eager": False}[a.launch])
         for i in range(warmup):
             one(i)
         if world > 1:
@@ -181,7 +181,8 @@ def main():
         "config": {"workload": f"trVAE synthetic {a.cells} cells x {G} HVG (CSR in HBM, "
                                f"{data.numel() / n_local:.0f} nnz/cell), {C} conditions, NB loss, MMD on z, hidden {H}, "
                                f"Z={Z}, dropout 0.05, Adam(eps 0.01, wd 0.04)",
-                   "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}" if world > 1 else "single"},
+                   "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}" if world > 1 else "single",
+                   "launch": a.launch},
         "final_losses": {"recon": losses[0], "kl": losses[1], "mmd": losses[2]},
     }
 

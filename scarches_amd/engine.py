@@ -531,12 +531,16 @@ class CVAEEngine:
 
     # ------------------------------------------------------------------------------------------ HIP-graph step
     def train_step(self, row_ids, cond, B, alpha_kl, lr, eps=0.01, clip=0.0, weight_decay=0.04, world=1,
-                   use_graph=True):
+                   use_graph="auto"):
         """One optimisation step: forward + backward (+ gradient all-reduce) + Adam.
 
         With use_graph the launch sequence of this batch size is captured once into HIP graphs (all per-step
         scalars live in device memory: `hyper`, `step_ctr`; minibatch ids are copied into static buffers) and
-        replayed: ~60 kernel launches cost one graph launch on the host."""
+        replayed: ~60 kernel launches cost one graph launch on the host.  "auto" replays graphs for B <= 2048
+        (launch-bound: 0.54 -> 0.39 ms at B=128) and launches eagerly above (GPU-bound; measured at B=4096 the
+        two-stream eager schedule is ~7% faster than the graph's dependency handling)."""
+        if use_graph == "auto":
+            use_graph = B <= 2048
         self.begin_step(alpha_kl, lr, eps, clip)
         if not use_graph:
             self.forward_backward(row_ids, cond, B)
