@@ -83,15 +83,18 @@ int sca_latent_bwd(const float* dz, int S, long long slab_stride, const float* d
  * losses.py:109-163) log-likelihood with counts read straight from CSR, and - when compute_grad - the gradient of
  * recon = -sum/B written IN PLACE over logits (and pi), theta gradients accumulated (unscaled sum_b theta*dll/dtheta)
  * into dthetaT[C][G] and the output-bias gradients into dbias[G] (both must be zeroed by the caller).
- * sca_mse_rows: ReLU head + sum of squares (trvae.py:125-127).
+ * cond_off (optional, [C][G]): per-condition offsets added to the logits on load - expiMap's single-layer decoder adds
+ * cond_L.weight[:, c_b] right before the softmax (models/expimap/modules.py:83-84, 142).
+ * sca_mse_rows: ReLU head (relu=1, trvae.py:125-127) or identity head (relu=0, expimap.py:182-184) + sum of squares.
  * sca_transpose_scale: dst[cols][rows] = scale * src[rows][cols] (dthetaT -> theta.grad layout [G][C]). */
 int sca_theta_prep(const float* theta, int G, int C, float* tab_theta, float* tab_lte, void* stream);
 int sca_recon_rows(int zinb, float* logits, int ldl, float* pi, const int64_t* indptr, const int32_t* indices,
                    const float* data, const int64_t* row_ids, const float* sizefactor, const int32_t* cond,
                    const float* tab_theta, const float* tab_lte, int B, int G, int C, int rows_per_block, float* row_ll,
-                   float* dthetaT, float* dbias, float* dbias_pi, int compute_grad, void* stream);
+                   float* dthetaT, float* dbias, float* dbias_pi, int compute_grad, const float* cond_off,
+                   void* stream);
 int sca_mse_rows(float* lin, int ldl, const float* x, int ldx, int B, int G, int rows_per_block, float* row_loss,
-                 float* dbias, int compute_grad, void* stream);
+                 float* dbias, int compute_grad, int relu, const int32_t* cond, const float* cond_off, void* stream);
 int sca_transpose_scale(const float* src, int rows, int cols, float scale, float* dst, void* stream);
 
 /* ---- MMD -----------------------------------------------------------------------------------------------------
@@ -113,6 +116,26 @@ int sca_adam_step(float* p, const float* g, float* m, float* v, long long n, con
                   float beta2, float weight_decay, void* stream);
 int sca_finalize_losses(const float* row_recon, float recon_sign, const float* row_kl, int B, const double* mmd_part,
                         int n_part, const float* hyper, float* losses, double* accum, void* stream);
+
+/* ---- expiMap ---------------------------------------------------------------------------------------------------
+ * sca_masked_copy: dst[r*ldd+c] = src[r*lds+c] * (mask ? mask[r*ldm+c] : 1).  Packs MaskedLinear weights
+ * (weight*mask, models/expimap/modules.py:24-25) of expr_L / ext_L_m / ext_L into ONE decoder matrix
+ * [G][L+n_ext_m+n_ext] (column order of MaskedCondLayers.forward, modules.py:62-85) and scatters the packed weight
+ * gradient back through the masks (autograd of weight*mask).
+ * sca_prox_l1 / sca_prox_group_lasso: ProxL1 / ProxGroupLasso (trainers/expimap/regularized.py:35-58, 5-32) in place
+ * on a [rows][cols] weight; I (optional) has the weight's shape, entries != 0 are left untouched; omega: [cols].
+ * sca_hsic_fwd_bwd: hsic(z[:, side==0], z[:, side==1]) (models/expimap/losses.py:23-31) with RBF bandwidths sigma_a /
+ * sigma_b (losses.py:15-21, computed by the caller); writes (accumulate=0) or adds (accumulate=1) weight*hsic into
+ * loss_weighted[0] (double) and hsic into loss_raw[0], and ADDS weight * d hsic / d z into dz (may be NULL).
+ * work: scratch of sca_hsic_workspace_floats(B) floats. */
+int sca_masked_copy(const float* src, int lds, const float* mask, int ldm, float* dst, int ldd, int rows, int cols,
+                    void* stream);
+int sca_prox_l1(float* W, long long n, float alpha, const float* I, void* stream);
+int sca_prox_group_lasso(float* W, int rows, int cols, float alpha, const float* omega, void* stream);
+long long sca_hsic_workspace_floats(int B);
+int sca_hsic_fwd_bwd(const float* z, int ld, int B, int D, const uint8_t* side, float sigma_a, float sigma_b,
+                     float weight, float* work, double* loss_weighted, float* loss_raw, int accumulate, float* dz,
+                     int lddz, void* stream);
 
 #ifdef __cplusplus
 }

@@ -35,15 +35,21 @@ SIGNATURES = {
     "sca_latent_fwd": [P, I, LL, P, I, I, P, U64, U32, P, I, P, P, P, P, P],
     "sca_latent_bwd": [P, I, LL, P, I, LL, P, P, P, I, I, P, P],
     "sca_theta_prep": [P, I, I, P, P, P],
-    "sca_recon_rows": [I, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, I, P],
-    "sca_mse_rows": [P, I, P, I, I, I, I, P, P, I, P],
+    "sca_recon_rows": [I, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, I, P, P],
+    "sca_mse_rows": [P, I, P, I, I, I, I, P, P, I, I, P, P, P],
     "sca_transpose_scale": [P, I, I, F, P, P],
     "sca_mmd_num_slabs": [I, I],
     "sca_mmd_num_partials": [I, I],
     "sca_mmd_fwd_bwd": [P, I, P, I, I, I, I, F, P, P, P, P, LL, P],
     "sca_adam_step": [P, P, P, P, LL, P, F, F, F, P],
     "sca_finalize_losses": [P, F, P, I, P, I, P, P, P, P],
+    "sca_masked_copy": [P, I, P, I, P, I, I, I, P],
+    "sca_prox_l1": [P, LL, F, P, P],
+    "sca_prox_group_lasso": [P, I, I, F, P, P],
+    "sca_hsic_workspace_floats": [I],
+    "sca_hsic_fwd_bwd": [P, I, I, I, P, F, F, F, P, P, P, I, P, I, P],
 }
+RESTYPES = {"sca_hsic_workspace_floats": LL}
 
 _lib = None
 
@@ -78,7 +84,7 @@ def load():
         except AttributeError as e:
             raise HipLibraryError(f"symbol {name} missing from {LIB_PATH}") from e
         fn.argtypes = argtypes
-        fn.restype = I
+        fn.restype = RESTYPES.get(name, I)
     _lib = lib
     return lib
 

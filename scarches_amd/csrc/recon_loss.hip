@@ -57,6 +57,8 @@ struct ReconArgs {
     float* dthetaT;                 // [C][G] accumulates sum_b theta * dll/dtheta (unscaled), pre-zeroed
     float* dbias; float* dbias_pi;  // [G] accumulate column sums of dlogits / dpi, pre-zeroed (may be null)
     int compute_grad;
+    const float* cond_off;          // optional [C][G]: per-condition logit offsets added on load (expiMap's
+                                    // decoder.L0.cond_L, scarches/models/expimap/modules.py:83-84), transposed
 };
 
 // ---- gamma-function terms of one stored count ---------------------------------------------------------------
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
         float* prow = ZINB ? a.pi + (long long)b * a.ldl : nullptr;
         const float* tth = a.tab_theta + (long long)c * G;
         const float* tlt = a.tab_lte + (long long)c * G;
+        const float* coff = a.cond_off ? a.cond_off + (long long)c * G : nullptr;
 
         // ---- online softmax statistics: per-thread (max, sum exp), merged across the workgroup in one round
         float lg[EPT];
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
             const int g = t + T * j;
-            lg[j] = g < G ? lrow[g] : -INFINITY;
+            lg[j] = g < G ? lrow[g] + (coff ? coff[g] : 0.f) : -INFINITY;
             mx = fmaxf(mx, lg[j]);
         }
         float se = 0.f;
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
             if (!(x > NB_EPS)) continue;
             const int g = a.indices[k];
             const float th = tth[g];
-            const float mu = __expf(lrow[g] - mx) * inv * s;
+            const float mu = __expf(lrow[g] + (coff ? coff[g] : 0.f) - mx) * inv * s;
             const float den = th + mu + NB_EPS;
             const float L = __logf(den), rr = __builtin_amdgcn_rcpf(den);
             float lgam = 0.f, dig = 0.f;
@@ -322,11 +325,13 @@ __global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
     }
 }
 
-// MSE head: out = relu(lin), loss_b = sum_g (out - x)^2 ; d lin = 2 (out - x) / B where lin > 0.
+// MSE head: out = relu(lin) (trVAE recon_decoder) or out = lin (+ per-condition offset; expiMap identity last layer,
+// scarches/models/expimap/expimap.py:182-184), loss_b = sum_g (out - x)^2 ; d lin = 2 (out - x) / B where active.
 __global__ __launch_bounds__(256) void mse_rows_kernel(float* __restrict__ lin, int ldl, const float* __restrict__ x,
                                                        int ldx, int B, int G, int rows_per_block,
                                                        float* __restrict__ row_loss, float* __restrict__ dbias,
-                                                       int compute_grad) {
+                                                       int compute_grad, int relu, const int32_t* __restrict__ cond,
+                                                       const float* __restrict__ cond_off) {
     __shared__ float red[16];
     const int b0 = blockIdx.x * rows_per_block, b1 = min(B, b0 + rows_per_block);
     const float invB = 1.0f / (float)B;
@@ -336,12 +341,13 @@ __global__ __launch_bounds__(256) void mse_rows_kernel(float* __restrict__ lin, 
         for (int b = b0; b < b1; ++b) {
             float sq = 0.f;
             if (g < G) {
-                const float l = lin[(long long)b * ldl + g];
-                const float o = fmaxf(l, 0.f);
+                float l = lin[(long long)b * ldl + g];
+                if (cond_off) l += cond_off[(long long)cond[b] * G + g];
+                const float o = relu ? fmaxf(l, 0.f) : l;
                 const float d = o - x[(long long)b * ldx + g];
                 sq = d * d;
                 if (compute_grad) {
-                    const float dl = l > 0.f ? 2.0f * d * invB : 0.f;
+                    const float dl = (!relu || l > 0.f) ? 2.0f * d * invB : 0.f;
                     lin[(long long)b * ldl + g] = dl;
                     accb += dl;
                 }
@@ -401,11 +407,13 @@ extern "C" int sca_recon_rows(int zinb, float* logits, int ldl, float* pi, const
                               const int32_t* indices, const float* data, const int64_t* row_ids,
                               const float* sizefactor, const int32_t* cond, const float* tab_theta,
                               const float* tab_lte, int B, int G, int C, int rows_per_block, float* row_ll,
-                              float* dthetaT, float* dbias, float* dbias_pi, int compute_grad, void* stream) {
+                              float* dthetaT, float* dbias, float* dbias_pi, int compute_grad,
+                              const float* cond_off, void* stream) {
     if (B <= 0) return 0;
     if (rows_per_block < 1 || ldl < G) return -1;
+    if (cond_off && !cond) return -1;
     ReconArgs a{logits, ldl, pi, indptr, indices, data, row_ids, sizefactor, cond, tab_theta, tab_lte,
-                B, G, C, rows_per_block, row_ll, dthetaT, dbias, dbias_pi, compute_grad};
+                B, G, C, rows_per_block, row_ll, dthetaT, dbias, dbias_pi, compute_grad, cond_off};
     const int rc = zinb ? launch_recon<true>(a, (hipStream_t)stream) : launch_recon<false>(a, (hipStream_t)stream);
     if (rc) return rc;
     SCA_CHECK_LAUNCH();
@@ -413,11 +421,13 @@ extern "C" int sca_recon_rows(int zinb, float* logits, int ldl, float* pi, const
 }
 
 extern "C" int sca_mse_rows(float* lin, int ldl, const float* x, int ldx, int B, int G, int rows_per_block,
-                            float* row_loss, float* dbias, int compute_grad, void* stream) {
+                            float* row_loss, float* dbias, int compute_grad, int relu, const int32_t* cond,
+                            const float* cond_off, void* stream) {
     if (B <= 0) return 0;
+    if (cond_off && !cond) return -1;
     const int nblk = (B + rows_per_block - 1) / rows_per_block;
     hipLaunchKernelGGL(mse_rows_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, lin, ldl, x, ldx, B, G,
-                       rows_per_block, row_loss, dbias, compute_grad);
+                       rows_per_block, row_loss, dbias, compute_grad, relu, cond, cond_off);
     SCA_CHECK_LAUNCH();
     return 0;
 }

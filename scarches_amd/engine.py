@@ -59,12 +59,35 @@ class CVAEEngine:
         self.seed = int(s.get("seed", 2020))
         assert self.recon in ("nb", "zinb", "mse")
         assert len(self.H) >= 1, "at least one hidden layer is required"
+        # architecture family: "trvae" (MLP decoder, one-hot conditions), "expimap" (single masked linear decoder
+        # layer + extension terms, scarches/models/expimap/expimap.py:44-171)
+        self.arch = s.get("arch", "trvae")
+        assert self.arch in ("trvae", "expimap")
+        self.n_ext, self.n_ext_m = int(s.get("n_ext", 0)), int(s.get("n_ext_m", 0))
+        self.Zx = self.n_ext + self.n_ext_m          # expand_{mean,var}_encoder width (ExtEncoder, modules.py:198-215)
+        self.Zt = self.Z + self.Zx                   # width of the sampled latent
+        self.use_hsic = bool(s.get("use_hsic", False)) and self.n_ext > 0
+        self.hsic_ova = bool(s.get("hsic_one_vs_all", False))
+        self.hsic_beta = float(s.get("hsic_beta", 1.0))
+        if self.arch == "expimap":
+            assert self.recon in ("nb", "mse")
+            if s.get("use_l_encoder", False):
+                raise NotImplementedError("use_l_encoder=True (library-size encoder) is not built in the HIP path")
+            last = s.get("decoder_last_layer") or ("softmax" if self.recon == "nb" else "identity")
+            if (self.recon, last) not in (("nb", "softmax"), ("mse", "identity")):
+                raise NotImplementedError("decoder_last_layer=%r with recon_loss=%r is not built in the HIP path "
+                                          "(softmax+nb and identity+mse are)" % (last, self.recon))
+            self.use_mmd = False
 
         # ---- flat parameter storage ------------------------------------------------------------------------
-        # mean/log_var heads are stored back to back so that both run as ONE [2Z, H] GEMM
+        # mean/log_var (+ expand) heads are stored back to back so that all run as ONE [2*Zt, H] GEMM whose output
+        # row is [mean | expand_mean | log_var | expand_var] = [means(Zt) | log_vars(Zt)]
         order = list(named_params.keys())
-        fused = ["encoder.mean_encoder.weight", "encoder.log_var_encoder.weight",
-                 "encoder.mean_encoder.bias", "encoder.log_var_encoder.bias"]
+        xw = self.Zx > 0
+        fused_w = (["encoder.mean_encoder.weight"] + (["encoder.expand_mean_encoder.weight"] if xw else [])
+                   + ["encoder.log_var_encoder.weight"] + (["encoder.expand_var_encoder.weight"] if xw else []))
+        fused_b = [k[:-6] + "bias" for k in fused_w]
+        fused = fused_w + fused_b
         order = [k for k in order if k not in fused]
         self.offsets: Dict[str, int] = {}
         self.shapes: Dict[str, tuple] = {}
@@ -73,7 +96,7 @@ class CVAEEngine:
             self.offsets[k] = off
             self.shapes[k] = tuple(named_params[k].shape)
             off = _round_up(off + named_params[k].numel(), ALIGN)
-        for pair in (fused[:2], fused[2:]):
+        for pair in (fused_w, fused_b):
             for k in pair:
                 self.offsets[k] = off
                 self.shapes[k] = tuple(named_params[k].shape)
@@ -108,19 +131,38 @@ class CVAEEngine:
                 self.enc.append(_Layer(f"enc{i}", f"encoder.FC.L{i}.weight", f"encoder.FC.L{i}.bias", None,
                                        H[i - 1], h, 10 + i, f"enc{i}"))
         Hd = list(reversed(H))
-        self.dec: List[_Layer] = [_Layer("dec0", "decoder.FirstL.L0.expr_L.weight", None,
-                                         "decoder.FirstL.L0.cond_L.weight" if has_c else None, Z, Hd[0], 40, "dec0")]
-        for i in range(1, len(Hd)):
-            self.dec.append(_Layer(f"dec{i}", f"decoder.HiddenL.L{i}.weight", None, None, Hd[i - 1], Hd[i], 40 + i,
-                                   f"dec{i}"))
-        if self.recon == "mse":
-            self.out_w, self.out_b = "decoder.recon_decoder.0.weight", "decoder.recon_decoder.0.bias"
+        self.dec: List[_Layer] = []
+        if self.arch == "expimap":
+            # one linear layer z[Zt] -> G; its weight is assembled per step from the (masked) pieces
+            self.xp_parts = [("decoder.L0.expr_L.weight", Z, s.get("mask"))]
+            if self.n_ext_m:
+                self.xp_parts.append(("decoder.L0.ext_L_m.weight", self.n_ext_m, s.get("ext_mask")))
+            if self.n_ext:
+                self.xp_parts.append(("decoder.L0.ext_L.weight", self.n_ext, None))
+            self.xp_masks = [None if m is None else m.detach().to(dev, torch.float32).contiguous()
+                             for (_, _, m) in self.xp_parts]
+            for (k, w, m), md in zip(self.xp_parts, self.xp_masks):
+                assert self.shapes[k] == (G, w), (k, self.shapes[k])
+                assert md is None or tuple(md.shape) == (G, w), "mask must be [G, n_terms] (MaskedLinear.mask layout)"
+            self.xp_wc = "decoder.L0.cond_L.weight" if has_c else None
+            self.out_w = self.out_b = None
         else:
-            self.out_w, self.out_b = "decoder.mean_decoder.0.weight", "decoder.mean_decoder.0.bias"
-        self.heads_w = self.flat_p[self.offsets[fused[0]]:self.offsets[fused[0]] + 2 * Z * H[-1]].view(2 * Z, H[-1])
-        self.heads_b = self.flat_p[self.offsets[fused[2]]:self.offsets[fused[2]] + 2 * Z]
-        self.heads_gw = self.flat_g[self.offsets[fused[0]]:self.offsets[fused[0]] + 2 * Z * H[-1]].view(2 * Z, H[-1])
-        self.heads_gb = self.flat_g[self.offsets[fused[2]]:self.offsets[fused[2]] + 2 * Z]
+            self.dec.append(_Layer("dec0", "decoder.FirstL.L0.expr_L.weight", None,
+                                   "decoder.FirstL.L0.cond_L.weight" if has_c else None, Z, Hd[0], 40, "dec0"))
+            for i in range(1, len(Hd)):
+                self.dec.append(_Layer(f"dec{i}", f"decoder.HiddenL.L{i}.weight", None, None, Hd[i - 1], Hd[i],
+                                       40 + i, f"dec{i}"))
+            if self.recon == "mse":
+                self.out_w, self.out_b = "decoder.recon_decoder.0.weight", "decoder.recon_decoder.0.bias"
+            else:
+                self.out_w, self.out_b = "decoder.mean_decoder.0.weight", "decoder.mean_decoder.0.bias"
+        Zt = self.Zt
+        ow, ob = self.offsets[fused_w[0]], self.offsets[fused_b[0]]
+        self.heads_w = self.flat_p[ow:ow + 2 * Zt * H[-1]].view(2 * Zt, H[-1])
+        self.heads_b = self.flat_p[ob:ob + 2 * Zt]
+        self.heads_gw = self.flat_g[ow:ow + 2 * Zt * H[-1]].view(2 * Zt, H[-1])
+        self.heads_gb = self.flat_g[ob:ob + 2 * Zt]
+        self.heads_names = fused
 
         # ---- small persistent device state -----------------------------------------------------------------
         self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
@@ -181,9 +223,10 @@ class CVAEEngine:
         if B <= self.Bcap:
             return
         dev, f32 = self.device, torch.float32
-        G, C, Z, H = self.G, max(self.C, 1), self.Z, self.H
+        G, C, Z, H = self.G, max(self.C, 1), self.Zt, self.H
         L = self.lib
         Hmax = max(H)
+        xp = self.arch == "expimap"
         ws = {}
         ws["x"] = torch.empty(B, G, dtype=f32, device=dev)
         ws["sf"] = torch.empty(B, dtype=f32, device=dev)
@@ -202,7 +245,27 @@ class CVAEEngine:
         ws["tab_theta"] = torch.empty(C, G, dtype=f32, device=dev)
         ws["tab_lte"] = torch.empty(C, G, dtype=f32, device=dev)
         ws["dthetaT"] = torch.empty(C, G, dtype=f32, device=dev)
-        ws["segT"] = torch.empty(C * max(Hmax, 2 * Z), dtype=f32, device=dev)
+        ws["segT"] = torch.empty(C * max(Hmax, 2 * Z, G if xp else 0), dtype=f32, device=dev)
+        if xp:
+            ws["Weff"] = torch.empty(G, Z, dtype=f32, device=dev)      # packed [expr*mask | ext_m*mask | ext]
+            ws["dWeff"] = torch.empty(G, Z, dtype=f32, device=dev)
+            ws["coffT"] = torch.empty(C, G, dtype=f32, device=dev)     # decoder cond_L.weight transposed
+            if self.use_hsic:
+                ws["hsic_work"] = torch.empty(L.sca_hsic_workspace_floats(B), dtype=f32, device=dev)
+                ws["hsic_dz"] = torch.empty(B, Z, dtype=f32, device=dev)
+                ws["hsic_raw"] = torch.zeros(1, dtype=f32, device=dev)
+                sides = []
+                if not self.hsic_ova:       # hsic(z[:, :-n_ext], z[:, -n_ext:]), expimap.py:205-208
+                    sides.append([0] * (Z - self.n_ext) + [1] * self.n_ext)
+                else:                       # each unconstrained term vs all the others, expimap.py:209-218
+                    shift = self.Z + self.n_ext_m
+                    for i in range(self.n_ext):
+                        sides.append([0 if k == shift + i else 1 for k in range(Z)])
+                ws["hsic_side"] = torch.tensor(sides, dtype=torch.uint8, device=dev)
+
+                def bw(d):          # RBF bandwidth of models/expimap/losses.py:15-21
+                    return 1.0 / (2.0 * (2.0 * math.gamma(0.5 * (d + 1)) / math.gamma(0.5 * d)) ** 2)
+                self._hsic_sigmas = [(bw(sd.count(0)), bw(sd.count(1))) for sd in sides]
         ws["da"] = torch.empty(B, max(Hmax, 2 * Z), dtype=f32, device=dev)
         ws["dheads"] = torch.empty(B, 2 * Z, dtype=f32, device=dev)
         # split-K slab workspace: the largest S*M*N over every GEMM of the step
@@ -211,15 +274,18 @@ class CVAEEngine:
         for ly in self.enc + self.dec:
             shapes += [(B, ly.n_out, ly.n_in), (ly.n_out, ly.n_in, B), (B, ly.n_in, ly.n_out)]
         shapes += [(B, 2 * Z, H[-1]), (2 * Z, H[-1], B), (B, H[-1], 2 * Z)]
-        Hl = self.dec[-1].n_out
-        shapes += [(G, Hl, B), (B, Hl, G)]
+        if xp:
+            shapes += [(G, Z, B), (B, Z, G)]
+        else:
+            Hl = self.dec[-1].n_out
+            shapes += [(G, Hl, B), (B, Hl, G)]
         for (M, N, K) in shapes:
             need = max(need, L.sca_gemm_splitk_heuristic(M, N, K) * M * N)
         ws["slab"] = torch.empty(need, dtype=f32, device=dev)
         ws["slab_aux"] = torch.empty(need, dtype=f32, device=dev)
         for ly in self.enc + self.dec:
             ws[ly.tag + ".da"] = torch.empty(B, ly.n_out, dtype=f32, device=dev)
-        Dm = Z if self.mmd_on == "z" else self.dec[0].n_out
+        Dm = Z if (self.mmd_on == "z" or xp) else self.dec[0].n_out
         self._mmd_ns = L.sca_mmd_num_slabs(B, Dm)
         ws["mmd_g"] = torch.empty(max(1, self._mmd_ns) * B * Dm, dtype=f32, device=dev)
         ws["mmd_part"] = torch.zeros(max(1, L.sca_mmd_num_partials(B, Dm)), dtype=torch.float64, device=dev)
@@ -294,12 +360,14 @@ class CVAEEngine:
         self._ensure(B)
         ws = self.ws
         st = torch.cuda.current_stream(self.device).cuda_stream
-        G, C, Z = self.G, self.C, self.Z
+        G, C, Z = self.G, self.C, self.Zt
         ptr = _lib.ptr
         p_drop = self.dr_rate if train else 0.0
         cond_p = ptr(cond) if C > 0 else None
         step_p = self.step_ctr.data_ptr()
         masks = masks or {}
+        self._mmd_ns_cur = 0
+        self._p_drop_cur, self._masks_cur = p_drop, masks
 
         # 1. minibatch gather (+ log1p, size factors)
         log1p = 0 if self.recon == "mse" else 1
@@ -346,6 +414,8 @@ class CVAEEngine:
         do_mmd = self.use_mmd and C > 0
         if do_mmd and self.mmd_on == "z":
             n_part = launch_mmd()
+        if self.arch == "expimap":
+            return self._expimap_tail(row_ids, cond_p, B, compute_grad, accumulate_logs, st)
         # 4. decoder
         a = ws["z"].data_ptr()
         for i, ly in enumerate(self.dec):
@@ -363,7 +433,7 @@ class CVAEEngine:
             _lib.check(L.sca_mse_rows(ws["logits"].data_ptr(), G, ws["x"].data_ptr(), G, B, G, rpb,
                                       ws["row_ll"].data_ptr(),
                                       self.g[self.out_b].data_ptr() if self.trainable[self.out_b] else None,
-                                      int(compute_grad), st),
+                                      int(compute_grad), 1, None, None, st),
                        "mse_rows")
             recon_sign = 1.0
         else:
@@ -385,7 +455,7 @@ class CVAEEngine:
                                         self.g[self.out_b].data_ptr() if self.trainable[self.out_b] else None,
                                         self.g["decoder.dropout_decoder.bias"].data_ptr()
                                         if zinb and self.trainable["decoder.dropout_decoder.bias"] else None,
-                                        int(compute_grad), st), "recon_rows")
+                                        int(compute_grad), None, st), "recon_rows")
             recon_sign = -1.0
         if n_part:
             self._join()          # MMD value (and gradient slabs) are ready
@@ -403,7 +473,7 @@ class CVAEEngine:
         stream; every weight / bias / condition-weight gradient only feeds Adam, so it is issued on the aux stream
         (own slab workspace, per-layer `da` buffers) and joined once at the end."""
         L, P, Gd, ws, T = self.lib, self.p, self.g, self.ws, self.trainable
-        G, C, Z = self.G, self.C, self.Z
+        G, C, Z = self.G, self.C, self.Zt
         ptr = _lib.ptr
         step_p = self.step_ctr.data_ptr()
         AUX = "slab_aux" if self.overlap else "slab"
@@ -431,28 +501,6 @@ class CVAEEngine:
             extra = scratch.data_ptr()
         sp, S, stride = self._gemm(0, 1, dl, G, P[self.out_w].data_ptr(), Hd, B, Hd, G, st)
 
-        def layer_backward(ly, a_prev, sp, S, stride, extra, need_dx):
-            m = masks.get(ly.mask_key)
-            da = ws[ly.tag + ".da"].data_ptr()
-            _lib.check(L.sca_layer_bwd(sp, S, stride, extra, B, ly.n_out, ws[ly.tag + ".yn"].data_ptr(),
-                                       ws[ly.tag + ".rs"].data_ptr(), self.norm, 1, p_drop, ptr(m), self.seed,
-                                       ly.rng_stream, step_p, da, st), "layer_bwd")
-            need_w = T[ly.w]
-            need_b = bool(ly.b) and T[ly.b]
-            need_c = bool(ly.wc) and T[ly.wc]
-            if need_w or need_b or need_c:
-                sa = self._fork()
-                if need_w:
-                    self._gemm_to(1, 1, da, ly.n_out, a_prev, ly.n_in, ly.n_out, ly.n_in, B, sa, Gd[ly.w],
-                                  slab_key=AUX)
-                if need_b or need_c:
-                    _lib.check(L.sca_cond_colsum(da, B, ly.n_out, cond_p if ly.wc else None, C if ly.wc else 0,
-                                                 ws["segT"].data_ptr(), Gd[ly.wc].data_ptr() if need_c else None,
-                                                 Gd[ly.b].data_ptr() if need_b else None, sa), "cond_colsum")
-            if need_dx:
-                return self._gemm(0, 1, da, ly.n_out, P[ly.w].data_ptr(), ly.n_in, B, ly.n_in, ly.n_out, st)
-            return None, 0, 0
-
         # ---- decoder, last -> first
         for li in range(len(self.dec) - 1, -1, -1):
             ly = self.dec[li]
@@ -464,31 +512,156 @@ class CVAEEngine:
                     ws["mmd_extra"].view(-1)[:B * ly.n_out].add_(self._scratch_bh(B, ly.n_out).view(-1))
                 extra = ws["mmd_extra"].data_ptr()
             a_prev = ws["z"].data_ptr() if li == 0 else ws[self.dec[li - 1].tag + ".h"].data_ptr()
-            sp, S, stride = layer_backward(ly, a_prev, sp, S, stride, extra, True)
+            sp, S, stride = self._layer_backward(ly, a_prev, sp, S, stride, extra, True, B, cond_p, p_drop, masks, st)
             extra = None
 
-        # ---- latent block: dz (decoder) + dz (MMD on z) + KL
         use_mz = have_mmd and self.mmd_on == "z"
-        _lib.check(L.sca_latent_bwd(sp, S, stride, ws["mmd_g"].data_ptr() if use_mz else None,
-                                    self._mmd_ns_cur if use_mz else 0, B * Z, ws["mu_lv"].data_ptr(),
+        self._backward_latent_encoder(B, cond_p, p_drop, masks, st, sp, S, stride,
+                                      ws["mmd_g"].data_ptr() if use_mz else None,
+                                      self._mmd_ns_cur if use_mz else 0)
+
+    def _layer_backward(self, ly, a_prev, sp, S, stride, extra, need_dx, B, cond_p, p_drop, masks, st):
+        """Gradient through one Linear(+cond) -> norm -> ReLU -> dropout block: `da` on the main stream, the weight /
+        bias / condition-weight gradients on the aux stream, then (need_dx) the dX GEMM slabs for the layer below."""
+        L, P, Gd, ws, T = self.lib, self.p, self.g, self.ws, self.trainable
+        C = self.C
+        ptr = _lib.ptr
+        AUX = "slab_aux" if self.overlap else "slab"
+        m = masks.get(ly.mask_key)
+        da = ws[ly.tag + ".da"].data_ptr()
+        _lib.check(L.sca_layer_bwd(sp, S, stride, extra, B, ly.n_out, ws[ly.tag + ".yn"].data_ptr(),
+                                   ws[ly.tag + ".rs"].data_ptr(), self.norm, 1, p_drop, ptr(m), self.seed,
+                                   ly.rng_stream, self.step_ctr.data_ptr(), da, st), "layer_bwd")
+        need_w = T[ly.w]
+        need_b = bool(ly.b) and T[ly.b]
+        need_c = bool(ly.wc) and T[ly.wc]
+        if need_w or need_b or need_c:
+            sa = self._fork()
+            if need_w:
+                self._gemm_to(1, 1, da, ly.n_out, a_prev, ly.n_in, ly.n_out, ly.n_in, B, sa, Gd[ly.w],
+                              slab_key=AUX)
+            if need_b or need_c:
+                _lib.check(L.sca_cond_colsum(da, B, ly.n_out, cond_p if ly.wc else None, C if ly.wc else 0,
+                                             ws["segT"].data_ptr(), Gd[ly.wc].data_ptr() if need_c else None,
+                                             Gd[ly.b].data_ptr() if need_b else None, sa), "cond_colsum")
+        if need_dx:
+            return self._gemm(0, 1, da, ly.n_out, P[ly.w].data_ptr(), ly.n_in, B, ly.n_in, ly.n_out, st)
+        return None, 0, 0
+
+    def _backward_latent_encoder(self, B, cond_p, p_drop, masks, st, sp, S, stride, dz2, S2):
+        """Latent block (dz from the decoder + dz2 from MMD / HSIC + KL) -> heads -> encoder layers, last -> first."""
+        L, ws, T = self.lib, self.ws, self.trainable
+        Z = self.Zt
+        AUX = "slab_aux" if self.overlap else "slab"
+        _lib.check(L.sca_latent_bwd(sp, S, stride, dz2, S2, B * Z, ws["mu_lv"].data_ptr(),
                                     ws["eps"].data_ptr(), self.hyper.data_ptr(), B, Z, ws["dheads"].data_ptr(), st),
                    "latent_bwd")
         Hl = self.H[-1]
         h_enc = ws[self.enc[-1].tag + ".h"].data_ptr()
         dh = ws["dheads"].data_ptr()
-        if T["encoder.mean_encoder.weight"]:
+        heads_t = [T[k] for k in self.heads_names]
+        if any(heads_t):
+            # mean / log_var (/ expand) heads share one fused gradient GEMM; a frozen member's slice of the result is
+            # simply never consumed by Adam (trainable_ranges() skips it)
             sa = self._fork()
             self._gemm_to(1, 1, dh, 2 * Z, h_enc, Hl, 2 * Z, Hl, B, sa, self.heads_gw, slab_key=AUX)
             _lib.check(L.sca_cond_colsum(dh, B, 2 * Z, None, 0, ws["segT"].data_ptr(), None,
                                          self.heads_gb.data_ptr(), sa), "heads_bias")
         sp, S, stride = self._gemm(0, 1, dh, 2 * Z, self.heads_w.data_ptr(), Hl, B, Hl, 2 * Z, st)
-
-        # ---- encoder, last -> first
         for li in range(len(self.enc) - 1, -1, -1):
             ly = self.enc[li]
             a_prev = ws["x"].data_ptr() if li == 0 else ws[self.enc[li - 1].tag + ".h"].data_ptr()
-            sp, S, stride = layer_backward(ly, a_prev, sp, S, stride, None, li > 0)
+            sp, S, stride = self._layer_backward(ly, a_prev, sp, S, stride, None, li > 0, B, cond_p, p_drop, masks,
+                                                 st)
         self._join()
+
+    # ------------------------------------------------------------------------------------------ expiMap
+    def _expimap_pack(self, st):
+        """Weff [G][Zt] = [expr_L.weight*mask | ext_L_m.weight*ext_mask | ext_L.weight] (column order of
+        MaskedCondLayers.forward) and the transposed condition weights."""
+        L, P, ws = self.lib, self.p, self.ws
+        Zt, col = self.Zt, 0
+        for (k, w, _), md in zip(self.xp_parts, self.xp_masks):
+            _lib.check(L.sca_masked_copy(P[k].data_ptr(), w, _lib.ptr(md), w, ws["Weff"].data_ptr() + 4 * col, Zt,
+                                         self.G, w, st), "masked_copy")
+            col += w
+        if self.xp_wc:
+            _lib.check(L.sca_transpose_scale(P[self.xp_wc].data_ptr(), self.G, self.C, 1.0,
+                                             ws["coffT"].data_ptr(), st), "cond_transpose")
+
+    def _expimap_tail(self, row_ids, cond_p, B, compute_grad, accumulate_logs, st):
+        """Decoder + losses + backward of expiMap after the latent block (models/expimap/expimap.py:180-222)."""
+        L, P, Gd, ws, T = self.lib, self.p, self.g, self.ws, self.trainable
+        G, C, Zt = self.G, self.C, self.Zt
+        ptr = _lib.ptr
+        AUX = "slab_aux" if self.overlap else "slab"
+        # HSIC between annotated and unconstrained latent columns, beside the decoder (aux stream)
+        n_part = 0
+        if self.use_hsic:
+            sa = self._fork()
+            if compute_grad:
+                with torch.cuda.stream(self.aux if self.overlap else torch.cuda.current_stream(self.device)):
+                    ws["hsic_dz"].zero_()
+            side = ws["hsic_side"]
+            for i, (sig_a, sig_b) in enumerate(self._hsic_sigmas):
+                _lib.check(L.sca_hsic_fwd_bwd(ws["z"].data_ptr(), Zt, B, Zt, side[i].data_ptr(), sig_a, sig_b,
+                                              self.hsic_beta, ws["hsic_work"].data_ptr(), ws["mmd_part"].data_ptr(),
+                                              ws["hsic_raw"].data_ptr(), int(i > 0),
+                                              ws["hsic_dz"].data_ptr() if compute_grad else None, Zt, sa), "hsic")
+            n_part = 1
+        self._expimap_pack(st)
+        coff = ws["coffT"].data_ptr() if self.xp_wc else None
+        self._gemm(0, 0, ws["z"].data_ptr(), Zt, ws["Weff"].data_ptr(), Zt, B, G, Zt, st,
+                   out=ws["logits"].data_ptr(), ldc=G, force_s1=True)
+        rpb = max(1, B // 1024)
+        if self.recon == "mse":
+            _lib.check(L.sca_mse_rows(ws["logits"].data_ptr(), G, ws["x"].data_ptr(), G, B, G, rpb,
+                                      ws["row_ll"].data_ptr(), None, int(compute_grad), 0, cond_p, coff, st),
+                       "mse_rows")
+            recon_sign = 1.0
+        else:
+            _lib.check(L.sca_theta_prep(P["theta"].data_ptr(), G, max(C, 1), ws["tab_theta"].data_ptr(),
+                                        ws["tab_lte"].data_ptr(), st), "theta_prep")
+            if compute_grad:
+                ws["dthetaT"].zero_()
+            ip, ix, dv = self.csr
+            _lib.check(L.sca_recon_rows(0, ws["logits"].data_ptr(), G, None, ip.data_ptr(), ix.data_ptr(),
+                                        dv.data_ptr(), ptr(row_ids), ws["sf"].data_ptr(), cond_p,
+                                        ws["tab_theta"].data_ptr(), ws["tab_lte"].data_ptr(), B, G, max(C, 1), rpb,
+                                        ws["row_ll"].data_ptr(), ws["dthetaT"].data_ptr(), None, None,
+                                        int(compute_grad), coff, st), "recon_rows")
+            recon_sign = -1.0
+        if n_part:
+            self._join()
+        _lib.check(L.sca_finalize_losses(ws["row_ll"].data_ptr(), recon_sign, ws["kl_row"].data_ptr(), B,
+                                         ws["mmd_part"].data_ptr(), n_part, self.hyper.data_ptr(),
+                                         self.losses.data_ptr(), self.accum.data_ptr() if accumulate_logs else None,
+                                         st), "finalize_losses")
+        if not compute_grad:
+            return self.losses
+        # ---- backward: weight-side gradients on the aux stream, dz on the main stream
+        dl = ws["logits"].data_ptr()
+        sa = self._fork()
+        if self.recon != "mse" and T["theta"]:
+            _lib.check(L.sca_transpose_scale(ws["dthetaT"].data_ptr(), max(C, 1), G, -1.0 / B,
+                                             Gd["theta"].data_ptr(), sa), "transpose_scale")
+        if any(T[k] for (k, _, _) in self.xp_parts):
+            self._gemm_to(1, 1, dl, G, ws["z"].data_ptr(), Zt, G, Zt, B, sa, ws["dWeff"], slab_key=AUX)
+            col = 0
+            for (k, w, _), md in zip(self.xp_parts, self.xp_masks):
+                if T[k]:
+                    _lib.check(L.sca_masked_copy(ws["dWeff"].data_ptr() + 4 * col, Zt, ptr(md), w,
+                                                 Gd[k].data_ptr(), w, G, w, sa), "masked_unpack")
+                col += w
+        if self.xp_wc and T[self.xp_wc]:
+            _lib.check(L.sca_cond_colsum(dl, B, G, cond_p, C, ws["segT"].data_ptr(), Gd[self.xp_wc].data_ptr(),
+                                         None, sa), "cond_colsum")
+        sp, S, stride = self._gemm(0, 1, dl, G, ws["Weff"].data_ptr(), Zt, B, Zt, G, st)
+        p_drop = self._p_drop_cur
+        self._backward_latent_encoder(B, cond_p, p_drop, self._masks_cur, st, sp, S, stride,
+                                      ws["hsic_dz"].data_ptr() if self.use_hsic else None,
+                                      1 if self.use_hsic else 0)
+        return self.losses
 
     def _scratch_bh(self, B, Hd):
         if not hasattr(self, "_sbh") or self._sbh.numel() < B * Hd:
@@ -497,15 +670,20 @@ class CVAEEngine:
 
     # ------------------------------------------------------------------------------------------ optimiser
     def trainable_ranges(self):
-        """Contiguous [start, end) ranges of the flat buffer covering the trainable tensors (merged)."""
-        spans = sorted((self.offsets[k], self.offsets[k] + int(np.prod(self.shapes[k]))) for k in self.names
-                       if self.trainable[k])
-        merged = []
-        for s, e in spans:
-            if merged and s <= _round_up(merged[-1][1], ALIGN):
+        """Contiguous [start, end) ranges of the flat buffer covering the trainable tensors: tensors that follow each
+        other in the buffer (only alignment padding between them) are merged, a frozen tensor always splits."""
+        items = sorted((self.offsets[k], self.offsets[k] + int(np.prod(self.shapes[k])), self.trainable[k])
+                       for k in self.names)
+        merged, open_run = [], False
+        for s, e, t in items:
+            if not t:
+                open_run = False
+                continue
+            if open_run:
                 merged[-1][1] = e
             else:
                 merged.append([s, e])
+                open_run = True
         return [(s, e) for s, e in merged]
 
     def adam_step(self, weight_decay=0.04, wd_overrides: Optional[Dict[str, float]] = None):
@@ -608,7 +786,7 @@ class CVAEEngine:
         ws = self.ws
         st = torch.cuda.current_stream(self.device).cuda_stream
         ptr = _lib.ptr
-        G, C, Z = self.G, self.C, self.Z
+        G, C, Z = self.G, self.C, self.Zt
         log1p = 0 if self.recon == "mse" else 1
         if x_dense is not None:
             _lib.check(L.sca_dense_gather_rows(ptr(x_dense), x_dense.stride(0), ptr(row_ids), B, G, log1p,

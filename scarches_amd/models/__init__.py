@@ -1,4 +1,6 @@
 from .trvae.trvae import trVAE
 from .trvae.trvae_model import TRVAE
+from .expimap.expimap import expiMap
+from .expimap.expimap_model import EXPIMAP
 
-__all__ = ["trVAE", "TRVAE"]
+__all__ = ["trVAE", "TRVAE", "expiMap", "EXPIMAP"]

@@ -12,12 +12,11 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ... import _lib
-from ...engine import CVAEEngine
+from ..base._engine_module import EngineBackedModule
 from .modules import Decoder, Encoder
 
 
-class trVAE(nn.Module):
+class trVAE(EngineBackedModule):
     def __init__(self,
                  input_dim: int,
                  conditions: list,
@@ -68,7 +67,7 @@ class trVAE(nn.Module):
                                self.n_conditions)
         self.decoder = Decoder(dec_sizes, self.latent_dim, self.recon_loss, self.use_bn, self.use_ln, self.use_dr,
                                self.dr_rate, self.n_conditions)
-        self._engine: Optional[CVAEEngine] = None
+        self._engine = None
         self.seed = 2020
 
     # ------------------------------------------------------------------------------------------ engine plumbing
@@ -78,65 +77,20 @@ class trVAE(nn.Module):
                     use_mmd=self.use_mmd, mmd_on=self.mmd_on, boundary=self.mmd_boundary, beta=float(self.beta),
                     seed=self.seed)
 
-    def engine(self, device=None) -> CVAEEngine:
-        """The HIP engine holding this network's parameters (created on first use; parameters then become views of
-        the engine's flat HBM buffer so state_dict()/load_state_dict()/requires_grad keep working on the real data)."""
-        if self._engine is None:
-            if device is None:
-                p = next(self.parameters())
-                device = p.device if p.device.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
-            if not torch.cuda.is_available():
-                raise _lib.HipLibraryError("no HIP device: scarches_amd has no CPU fallback")
-            named = OrderedDict((k, p.detach()) for k, p in self.named_parameters())
-            eng = CVAEEngine(self._spec(), named, device)
-            for k, p in self.named_parameters():
-                p.data = eng.p[k]
-            self._engine = eng
-        self._sync_engine_flags()
-        return self._engine
-
     def _sync_engine_flags(self):
+        super()._sync_engine_flags()
         eng = self._engine
-        eng.set_trainable([k for k, p in self.named_parameters() if p.requires_grad])
         eng.use_mmd, eng.beta, eng.boundary, eng.mmd_on = self.use_mmd, float(self.beta), self.mmd_boundary, self.mmd_on
-
-    def _apply(self, fn, *args, **kwargs):
-        # .cuda() / .to(device): moving would detach the parameters from the flat buffer, so rebuild the engine lazily
-        if self._engine is not None:
-            for k, p in self.named_parameters():
-                p.data = p.data.clone()
-            self._engine = None
-        return super()._apply(fn, *args, **kwargs)
 
     # ------------------------------------------------------------------------------------------ reference API
     def forward(self, x=None, batch=None, sizefactor=None, labeled=None):
         """(recon_loss, kl_div, mmd_loss) for a dense minibatch `x` [B, G] on the HIP device (no autograd graph).
         Train mode samples dropout masks / z like the reference; sizefactor is recomputed from x (== x.sum(1))."""
-        eng = self.engine(x.device if x.is_cuda else None)
-        x = x.to(eng.device, torch.float32).contiguous()
-        B = x.shape[0]
-        csr = x.to_sparse_csr()
-        eng.bind_csr(csr.crow_indices().to(torch.int64), csr.col_indices().to(torch.int32), csr.values())
+        eng, x, B = self._bind_dense(x)
         cond = None if batch is None else batch.to(eng.device).to(torch.int32).contiguous()
         eng.forward_backward(None, cond, B, train=self.training, compute_grad=False, accumulate_logs=False)
         L = eng.losses.clone()
         return L[0], L[1], L[2]
-
-    def sampling(self, mu, log_var):
-        """z = mu + eps * sqrt(exp(log_var) + 1e-4), eps ~ N(0, 1) (models/base/_base.py:391-407)."""
-        var = torch.exp(log_var) + 1e-4
-        return mu + torch.randn_like(mu) * var.sqrt()
-
-    def get_latent(self, x, c=None, mean=False, mean_var=False):
-        eng = self.engine(x.device if x.is_cuda else None)
-        x = x.to(eng.device, torch.float32).contiguous()
-        cond = None if c is None else c.to(eng.device).to(torch.int32).contiguous()
-        z, mu, var = eng.encode(None, cond, x.shape[0], mean=False, x_dense=x)
-        if mean:
-            return mu.clone()
-        if mean_var:
-            return mu.clone(), var.clone()
-        return z.clone()
 
     def get_y(self, x, c=None):
         eng = self.engine(x.device if x.is_cuda else None)

@@ -1,3 +1,4 @@
 from .trvae.unsupervised import trVAETrainer
+from .expimap.regularized import expiMapTrainer
 
-__all__ = ["trVAETrainer"]
+__all__ = ["trVAETrainer", "expiMapTrainer"]
