@@ -137,6 +137,35 @@ int sca_hsic_fwd_bwd(const float* z, int ld, int B, int D, const uint8_t* side, 
                      float weight, float* work, double* loss_weighted, float* loss_raw, int accumulate, float* dz,
                      int lddz, void* stream);
 
+/* ---- scPoli ----------------------------------------------------------------------------------------------------
+ * sca_embed_lookup: out[b][0..E) = W[idx[b*stride]][0..E) after renormalising the touched rows of W [n][E] in place
+ * to L2 norm <= max_norm (nn.Embedding(max_norm), models/scpoli/scpoli.py:99-101,137; max_norm <= 0: no renorm).
+ * flags: zeroed scratch of n bytes (left zeroed).  sca_embed_scatter_add: dW[idx[b*stride]][:] += ga[b][:] + gb[b][:]
+ * (autograd of the lookup; dW pre-zeroed by the caller, ga / gb may be NULL).
+ * sca_proto_loss: prototype_labeled_loss (labels [B][n_levels], -1 = unknown, rows with labeled[b] == 0 skipped) and
+ * prototype_unlabeled_loss (trainers/scpoli/trainer.py:721-773, p = 2): loss_weighted[0] = weight*labeled +
+ * weight_u*unlabeled (double), raw[0] / raw[1] (+)= the two unweighted values, dz [B][Z] = d(loss_weighted)/dz
+ * (overwritten), dPu (+)= d unlabeled / d Pu (pre-zeroed, may be NULL).  P or Pu may be NULL.  work: scratch of
+ * sca_proto_workspace_bytes(B, K, Ku) bytes.
+ * sca_class_moments: fp64 per-class count / sum z / sum z z^T over the (row, level) entries of labels (rows with
+ * sel[b] == 0 skipped), ACCUMULATED into pre-zeroed cnt[K], sum[K][Z], outer[K][Z][Z] - the quantities DP ranks
+ * all-reduce.  sca_class_moments_finish: mean / unbiased covariance (trainers/scpoli/trainer.py:667-719,
+ * _utils.py:237-282) for classes with cnt > 0 and update[v] != 0 (update NULL = all), else the previous values. */
+int sca_embed_lookup(float* W, int n, int E, const int32_t* idx, int stride, int B, float max_norm, uint8_t* flags,
+                     float* out, int ldo, void* stream);
+int sca_embed_scatter_add(const float* ga, const float* gb, int ldg, int B, int E, int n, const int32_t* idx,
+                          int stride, float* dW, void* stream);
+long long sca_proto_workspace_bytes(int B, int K, int Ku);
+int sca_proto_loss(const float* z, int ld, int B, int Z, const float* P, int K, const int32_t* labels, int n_levels,
+                   const uint8_t* labeled, float weight, const float* Pu, int Ku, float weight_u, void* work,
+                   double* loss_weighted, float* raw, int accumulate_raw, float* dz, int lddz, float* dPu,
+                   void* stream);
+int sca_class_moments(const float* z, int ld, int N, int Z, const int32_t* labels, int n_levels, const uint8_t* sel,
+                      int K, double* cnt, double* sum, double* outer, void* stream);
+int sca_class_moments_finish(const double* cnt, const double* sum, const double* outer, int K, int Z,
+                             const float* prev_mean, const float* prev_cov, const uint8_t* update, float* mean,
+                             float* cov, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -48,8 +48,14 @@ SIGNATURES = {
     "sca_prox_group_lasso": [P, I, I, F, P, P],
     "sca_hsic_workspace_floats": [I],
     "sca_hsic_fwd_bwd": [P, I, I, I, P, F, F, F, P, P, P, I, P, I, P],
+    "sca_embed_lookup": [P, I, I, P, I, I, F, P, P, I, P],
+    "sca_embed_scatter_add": [P, P, I, I, I, I, P, I, P, P],
+    "sca_proto_workspace_bytes": [I, I, I],
+    "sca_proto_loss": [P, I, I, I, P, I, P, I, P, F, P, I, F, P, P, P, I, P, I, P, P],
+    "sca_class_moments": [P, I, I, I, P, I, P, I, P, P, P, P],
+    "sca_class_moments_finish": [P, P, P, I, I, P, P, P, P, P, P],
 }
-RESTYPES = {"sca_hsic_workspace_floats": LL}
+RESTYPES = {"sca_hsic_workspace_floats": LL, "sca_proto_workspace_bytes": LL}
 
 _lib = None
 

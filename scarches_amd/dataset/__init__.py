@@ -1,3 +1,4 @@
 from .trvae.anndata import AnnotatedDataset as trVAEDataset
+from .scpoli.anndata import MultiConditionAnnotatedDataset
 
-__all__ = ["trVAEDataset"]
+__all__ = ["trVAEDataset", "MultiConditionAnnotatedDataset"]

@@ -62,7 +62,7 @@ class CVAEEngine:
         # architecture family: "trvae" (MLP decoder, one-hot conditions), "expimap" (single masked linear decoder
         # layer + extension terms, scarches/models/expimap/expimap.py:44-171)
         self.arch = s.get("arch", "trvae")
-        assert self.arch in ("trvae", "expimap")
+        assert self.arch in ("trvae", "expimap", "scpoli")
         self.n_ext, self.n_ext_m = int(s.get("n_ext", 0)), int(s.get("n_ext_m", 0))
         self.Zx = self.n_ext + self.n_ext_m          # expand_{mean,var}_encoder width (ExtEncoder, modules.py:198-215)
         self.Zt = self.Z + self.Zx                   # width of the sampled latent
@@ -78,6 +78,18 @@ class CVAEEngine:
                 raise NotImplementedError("decoder_last_layer=%r with recon_loss=%r is not built in the HIP path "
                                           "(softmax+nb and identity+mse are)" % (last, self.recon))
             self.use_mmd = False
+        # scPoli: conditions enter as dense embedding vectors (hstack of nn.Embedding lookups, one table per
+        # covariate); theta is indexed by the combined condition (scarches/models/scpoli/scpoli.py:99-101,137,161-176)
+        self.cond_embed = self.arch == "scpoli"
+        self.emb = []
+        if self.cond_embed:
+            self.E_list, self.n_conds = [int(e) for e in s["E"]], [int(n) for n in s["n_conds"]]
+            self.E = sum(self.E_list)
+            self.inject = set(s.get("inject", ["encoder", "decoder"]))
+            mn = s.get("max_norm", 1.0)
+            self.max_norm = 0.0 if mn is None else float(mn)
+            self.use_mmd = False
+            self.emb = [(f"embeddings.{i}.weight", n, e) for i, (n, e) in enumerate(zip(self.n_conds, self.E_list))]
 
         # ---- flat parameter storage ------------------------------------------------------------------------
         # mean/log_var (+ expand) heads are stored back to back so that all run as ONE [2*Zt, H] GEMM whose output
@@ -122,11 +134,16 @@ class CVAEEngine:
         # ---- layer table -----------------------------------------------------------------------------------
         H, G, Z = self.H, self.G, self.Z
         has_c = self.C > 0
+        has_c_enc = has_c_dec = has_c
+        if self.cond_embed:
+            has_c_enc = self.E > 0 and "encoder" in self.inject
+            has_c_dec = self.E > 0 and "decoder" in self.inject
         self.enc: List[_Layer] = []
         for i, h in enumerate(H):
             if i == 0:
                 self.enc.append(_Layer(f"enc{i}", "encoder.FC.L0.expr_L.weight", "encoder.FC.L0.expr_L.bias",
-                                       "encoder.FC.L0.cond_L.weight" if has_c else None, G, h, 10 + i, f"enc{i}"))
+                                       "encoder.FC.L0.cond_L.weight" if has_c_enc else None, G, h, 10 + i,
+                                       f"enc{i}"))
             else:
                 self.enc.append(_Layer(f"enc{i}", f"encoder.FC.L{i}.weight", f"encoder.FC.L{i}.bias", None,
                                        H[i - 1], h, 10 + i, f"enc{i}"))
@@ -148,7 +165,7 @@ class CVAEEngine:
             self.out_w = self.out_b = None
         else:
             self.dec.append(_Layer("dec0", "decoder.FirstL.L0.expr_L.weight", None,
-                                   "decoder.FirstL.L0.cond_L.weight" if has_c else None, Z, Hd[0], 40, "dec0"))
+                                   "decoder.FirstL.L0.cond_L.weight" if has_c_dec else None, Z, Hd[0], 40, "dec0"))
             for i in range(1, len(Hd)):
                 self.dec.append(_Layer(f"dec{i}", f"decoder.HiddenL.L{i}.weight", None, None, Hd[i - 1], Hd[i],
                                        40 + i, f"dec{i}"))
@@ -246,6 +263,14 @@ class CVAEEngine:
         ws["tab_lte"] = torch.empty(C, G, dtype=f32, device=dev)
         ws["dthetaT"] = torch.empty(C, G, dtype=f32, device=dev)
         ws["segT"] = torch.empty(C * max(Hmax, 2 * Z, G if xp else 0), dtype=f32, device=dev)
+        if self.cond_embed:
+            E = max(self.E, 1)
+            ws["cvec"] = torch.zeros(B, E, dtype=f32, device=dev)
+            ws["dcvec_enc"] = torch.empty(B, E, dtype=f32, device=dev)
+            ws["dcvec_dec"] = torch.empty(B, E, dtype=f32, device=dev)
+            ws["emb_flags"] = torch.zeros(max(self.n_conds + [1]), dtype=torch.uint8, device=dev)
+            ws["proto_dz"] = torch.empty(B, Z, dtype=f32, device=dev)
+            ws["proto_raw"] = torch.zeros(2, dtype=f32, device=dev)
         if xp:
             ws["Weff"] = torch.empty(G, Z, dtype=f32, device=dev)      # packed [expr*mask | ext_m*mask | ext]
             ws["dWeff"] = torch.empty(G, Z, dtype=f32, device=dev)
@@ -274,6 +299,10 @@ class CVAEEngine:
         for ly in self.enc + self.dec:
             shapes += [(B, ly.n_out, ly.n_in), (ly.n_out, ly.n_in, B), (B, ly.n_in, ly.n_out)]
         shapes += [(B, 2 * Z, H[-1]), (2 * Z, H[-1], B), (B, H[-1], 2 * Z)]
+        if self.cond_embed:
+            for ly in self.enc + self.dec:
+                if ly.wc:
+                    shapes += [(B, self.E, ly.n_out), (ly.n_out, self.E, B)]
         if xp:
             shapes += [(G, Z, B), (B, Z, G)]
         else:
@@ -352,7 +381,8 @@ class CVAEEngine:
     def forward_backward(self, row_ids: Optional[torch.Tensor], cond: Optional[torch.Tensor], B: int, train=True,
                          compute_grad=True, eps: Optional[torch.Tensor] = None,
                          masks: Optional[Dict[str, torch.Tensor]] = None, accumulate_logs=True,
-                         x_dense: Optional[torch.Tensor] = None):
+                         x_dense: Optional[torch.Tensor] = None, covs: Optional[torch.Tensor] = None,
+                         proto: Optional[dict] = None):
         """One fwd(+bwd) pass over the minibatch `row_ids` (int64 device tensor of CSR row numbers) whose conditions
         are `cond` (int32 device tensor).  Leaves losses in self.losses = [recon, kl, mmd, total] and, when
         compute_grad, the gradients of recon + hyper[0]*kl + mmd in self.flat_g.  Nothing is synchronised."""
@@ -379,11 +409,18 @@ class CVAEEngine:
             _lib.check(L.sca_csr_gather_rows(ip.data_ptr(), ix.data_ptr(), dv.data_ptr(), ptr(row_ids), B, G, log1p,
                                              ws["x"].data_ptr(), G, ws["sf"].data_ptr(), st), "csr_gather")
 
+        self._covs_cur = covs
+        if self.cond_embed:
+            self._embed_lookup(covs, B, st)
+            cw, cwp, cvec_p, cE = 0, None, ws["cvec"].data_ptr(), self.E
+        else:
+            cw, cwp, cvec_p, cE = C, cond_p, None, 0
+
         def layer_forward(ly, a_in):
             sp, S, stride = self._gemm(0, 0, a_in, ly.n_in, P[ly.w].data_ptr(), ly.n_in, B, ly.n_out, ly.n_in, st)
             m = masks.get(ly.mask_key)
             _lib.check(L.sca_layer_fwd(sp, S, stride, B, ly.n_out, ptr(P[ly.b]) if ly.b else None,
-                                       ptr(P[ly.wc]) if ly.wc else None, C, cond_p, None, 0, self.norm, 1, p_drop,
+                                       ptr(P[ly.wc]) if ly.wc else None, cw, cwp, cvec_p, cE, self.norm, 1, p_drop,
                                        ptr(m), self.seed, ly.rng_stream, step_p, ws[ly.tag + ".yn"].data_ptr(),
                                        ws[ly.tag + ".rs"].data_ptr(), ws[ly.tag + ".h"].data_ptr(), st), "layer_fwd")
             return ws[ly.tag + ".h"].data_ptr()
@@ -414,6 +451,9 @@ class CVAEEngine:
         do_mmd = self.use_mmd and C > 0
         if do_mmd and self.mmd_on == "z":
             n_part = launch_mmd()
+        self._dz2_cur = (None, 0)
+        if self.cond_embed and proto is not None:
+            n_part = self._launch_proto(proto, B, compute_grad)
         if self.arch == "expimap":
             return self._expimap_tail(row_ids, cond_p, B, compute_grad, accumulate_logs, st)
         # 4. decoder
@@ -458,14 +498,14 @@ class CVAEEngine:
                                         int(compute_grad), None, st), "recon_rows")
             recon_sign = -1.0
         if n_part:
-            self._join()          # MMD value (and gradient slabs) are ready
+            self._join()          # MMD / prototype-loss value (and gradient) are ready
         _lib.check(L.sca_finalize_losses(ws["row_ll"].data_ptr(), recon_sign, ws["kl_row"].data_ptr(), B,
                                          ws["mmd_part"].data_ptr(), n_part, self.hyper.data_ptr(),
                                          self.losses.data_ptr(), self.accum.data_ptr() if accumulate_logs else None,
                                          st), "finalize_losses")
         if not compute_grad:
             return self.losses
-        self._backward(B, cond_p, p_drop, masks, st, n_part > 0)
+        self._backward(B, cond_p, p_drop, masks, st, n_part > 0 and do_mmd)
         return self.losses
 
     def _backward(self, B, cond_p, p_drop, masks, st, have_mmd):
@@ -516,9 +556,8 @@ class CVAEEngine:
             extra = None
 
         use_mz = have_mmd and self.mmd_on == "z"
-        self._backward_latent_encoder(B, cond_p, p_drop, masks, st, sp, S, stride,
-                                      ws["mmd_g"].data_ptr() if use_mz else None,
-                                      self._mmd_ns_cur if use_mz else 0)
+        dz2, S2 = (ws["mmd_g"].data_ptr(), self._mmd_ns_cur) if use_mz else self._dz2_cur
+        self._backward_latent_encoder(B, cond_p, p_drop, masks, st, sp, S, stride, dz2, S2)
 
     def _layer_backward(self, ly, a_prev, sp, S, stride, extra, need_dx, B, cond_p, p_drop, masks, st):
         """Gradient through one Linear(+cond) -> norm -> ReLU -> dropout block: `da` on the main stream, the weight /
@@ -540,10 +579,23 @@ class CVAEEngine:
             if need_w:
                 self._gemm_to(1, 1, da, ly.n_out, a_prev, ly.n_in, ly.n_out, ly.n_in, B, sa, Gd[ly.w],
                               slab_key=AUX)
-            if need_b or need_c:
+            if self.cond_embed:
+                if need_c:       # dWc [H, E] = da^T @ cvec
+                    self._gemm_to(1, 1, da, ly.n_out, ws["cvec"].data_ptr(), self.E, ly.n_out, self.E, B, sa,
+                                  Gd[ly.wc], slab_key=AUX)
+                if need_b:
+                    _lib.check(L.sca_cond_colsum(da, B, ly.n_out, None, 0, ws["segT"].data_ptr(), None,
+                                                 Gd[ly.b].data_ptr(), sa), "bias_colsum")
+            elif need_b or need_c:
                 _lib.check(L.sca_cond_colsum(da, B, ly.n_out, cond_p if ly.wc else None, C if ly.wc else 0,
                                              ws["segT"].data_ptr(), Gd[ly.wc].data_ptr() if need_c else None,
                                              Gd[ly.b].data_ptr() if need_b else None, sa), "cond_colsum")
+        if self.cond_embed and ly.wc and any(T[k] for (k, _, _) in self.emb):
+            # gradient w.r.t. the dense condition vector: dcvec [B, E] = da @ Wc  (scattered into the embedding
+            # tables at the end of the backward pass)
+            sa = self._fork()
+            self._gemm_to(0, 1, da, ly.n_out, P[ly.wc].data_ptr(), self.E, B, self.E, ly.n_out, sa,
+                          ws["dcvec_enc" if ly.tag.startswith("enc") else "dcvec_dec"], slab_key=AUX)
         if need_dx:
             return self._gemm(0, 1, da, ly.n_out, P[ly.w].data_ptr(), ly.n_in, B, ly.n_in, ly.n_out, st)
         return None, 0, 0
@@ -573,7 +625,65 @@ class CVAEEngine:
             a_prev = ws["x"].data_ptr() if li == 0 else ws[self.enc[li - 1].tag + ".h"].data_ptr()
             sp, S, stride = self._layer_backward(ly, a_prev, sp, S, stride, None, li > 0, B, cond_p, p_drop, masks,
                                                  st)
+        if self.cond_embed and any(T[k] for (k, _, _) in self.emb):
+            self._embed_scatter(B)
         self._join()
+
+    # ------------------------------------------------------------------------------------------ scPoli
+    def _embed_lookup(self, covs, B, st):
+        """cvec [B, E] = hstack_i embeddings[i][covs[:, i]] with in-place max_norm renormalisation of touched rows."""
+        L, ws = self.lib, self.ws
+        if not self.emb:
+            return
+        assert covs is not None and covs.dtype == torch.int32 and covs.is_contiguous() and covs.shape[1] == len(self.emb)
+        col = 0
+        for i, (k, n, e) in enumerate(self.emb):
+            _lib.check(L.sca_embed_lookup(self.p[k].data_ptr(), n, e, covs.data_ptr() + 4 * i, len(self.emb), B,
+                                          self.max_norm, ws["emb_flags"].data_ptr(), ws["cvec"].data_ptr() + 4 * col,
+                                          self.E, st), "embed_lookup")
+            col += e
+
+    def _embed_scatter(self, B):
+        """Embedding gradients: scatter-add of dcvec (encoder + decoder injection sites) on the aux stream."""
+        L, ws, Gd, T = self.lib, self.ws, self.g, self.trainable
+        sa = self._fork()
+        covs = self._covs_cur
+        ga = ws["dcvec_enc"].data_ptr() if self.enc[0].wc else None
+        gb = ws["dcvec_dec"].data_ptr() if self.dec[0].wc else None
+        col = 0
+        with torch.cuda.stream(self.aux if self.overlap else torch.cuda.current_stream(self.device)):
+            for i, (k, n, e) in enumerate(self.emb):
+                if T[k]:
+                    Gd[k].zero_()
+                    _lib.check(L.sca_embed_scatter_add(None if ga is None else ga + 4 * col,
+                                                       None if gb is None else gb + 4 * col, self.E, B, e, n,
+                                                       covs.data_ptr() + 4 * i, len(self.emb), Gd[k].data_ptr(), sa),
+                               "embed_scatter")
+                col += e
+
+    def _launch_proto(self, proto, B, compute_grad):
+        """eta * (labeled + unlabeled_weight * unlabeled) prototype loss on z (trainers/scpoli/trainer.py:542-575) on the
+        aux stream; its value lands in the third loss slot, its gradient joins dz in latent_bwd."""
+        L, ws = self.lib, self.ws
+        Pl, Pu = proto.get("P"), proto.get("Pu")
+        if Pl is None and Pu is None:
+            return 0
+        K = 0 if Pl is None else Pl.shape[0]
+        Ku = 0 if Pu is None else Pu.shape[0]
+        need = L.sca_proto_workspace_bytes(B, K, Ku)
+        if "proto_work" not in ws or ws["proto_work"].numel() < need:
+            ws["proto_work"] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ct, lab = proto.get("celltypes"), proto.get("labeled")
+        eta, uw = float(proto.get("eta", 1.0)), float(proto.get("unlabeled_weight", 0.0))
+        sa = self._fork()
+        _lib.check(L.sca_proto_loss(ws["z"].data_ptr(), self.Zt, B, self.Zt, _lib.ptr(Pl), K, _lib.ptr(ct),
+                                    0 if ct is None else ct.shape[1], _lib.ptr(lab), eta, _lib.ptr(Pu), Ku, eta * uw,
+                                    ws["proto_work"].data_ptr(), ws["mmd_part"].data_ptr(),
+                                    ws["proto_raw"].data_ptr(), 1,
+                                    ws["proto_dz"].data_ptr() if compute_grad else None, self.Zt, None, sa), "proto")
+        if compute_grad:
+            self._dz2_cur = (ws["proto_dz"].data_ptr(), 1)
+        return 1
 
     # ------------------------------------------------------------------------------------------ expiMap
     def _expimap_pack(self, st):
@@ -669,43 +779,35 @@ class CVAEEngine:
         return self._sbh[:B * Hd].view(B, Hd)
 
     # ------------------------------------------------------------------------------------------ optimiser
-    def trainable_ranges(self):
-        """Contiguous [start, end) ranges of the flat buffer covering the trainable tensors: tensors that follow each
-        other in the buffer (only alignment padding between them) are merged, a frozen tensor always splits."""
-        items = sorted((self.offsets[k], self.offsets[k] + int(np.prod(self.shapes[k])), self.trainable[k])
-                       for k in self.names)
-        merged, open_run = [], False
-        for s, e, t in items:
+    def trainable_ranges(self, weight_decay=0.0, wd_overrides: Optional[Dict[str, float]] = None):
+        """Contiguous [start, end, wd) ranges of the flat buffer covering the trainable tensors: tensors that follow
+        each other in the buffer (only alignment padding between them) and share a weight decay are merged; a frozen
+        tensor always splits."""
+        wd_overrides = wd_overrides or {}
+        items = sorted((self.offsets[k], self.offsets[k] + int(np.prod(self.shapes[k])), self.trainable[k],
+                        float(wd_overrides.get(k, weight_decay))) for k in self.names)
+        merged, open_wd = [], None
+        for s, e, t, wd in items:
             if not t:
-                open_run = False
+                open_wd = None
                 continue
-            if open_run:
+            if open_wd is not None and open_wd == wd:
                 merged[-1][1] = e
             else:
-                merged.append([s, e])
-                open_run = True
-        return [(s, e) for s, e in merged]
+                merged.append([s, e, wd])
+                open_wd = wd
+        return [(s, e, wd) for s, e, wd in merged]
 
     def adam_step(self, weight_decay=0.04, wd_overrides: Optional[Dict[str, float]] = None):
         """One torch.optim.Adam-equivalent update of every trainable tensor; hyper[] must hold lr / bias corrections
-        for step t = self.adam_t + 1 (call begin_step first)."""
+        for step t = self.adam_t + 1 (call begin_step first).  wd_overrides: per-tensor weight decay (scPoli keeps its
+        embeddings in a weight_decay=0 parameter group, trainers/scpoli/trainer.py:297-305)."""
         L = self.lib
         st = torch.cuda.current_stream(self.device).cuda_stream
-        if wd_overrides:
-            # per-tensor weight decay (scPoli: embeddings 0): one launch per tensor
-            for k in self.names:
-                if not self.trainable[k]:
-                    continue
-                o, n = self.offsets[k], int(np.prod(self.shapes[k]))
-                wd = wd_overrides.get(k, weight_decay)
-                _lib.check(L.sca_adam_step(self.flat_p[o:].data_ptr(), self.flat_g[o:].data_ptr(),
-                                           self.flat_m[o:].data_ptr(), self.flat_v[o:].data_ptr(), n,
-                                           self.hyper.data_ptr(), 0.9, 0.999, wd, st), "adam")
-            return
-        for s, e in self.trainable_ranges():
+        for s, e, wd in self.trainable_ranges(weight_decay, wd_overrides):
             _lib.check(L.sca_adam_step(self.flat_p[s:].data_ptr(), self.flat_g[s:].data_ptr(),
                                        self.flat_m[s:].data_ptr(), self.flat_v[s:].data_ptr(), e - s,
-                                       self.hyper.data_ptr(), 0.9, 0.999, weight_decay, st), "adam")
+                                       self.hyper.data_ptr(), 0.9, 0.999, wd, st), "adam")
 
     # ------------------------------------------------------------------------------------------ HIP-graph step
     def train_step(self, row_ids, cond, B, alpha_kl, lr, eps=0.01, clip=0.0, weight_decay=0.04, world=1,
@@ -779,7 +881,7 @@ class CVAEEngine:
         self.step_ctr += 1
 
     # ------------------------------------------------------------------------------------------ inference
-    def encode(self, row_ids, cond, B, mean=True, x_dense=None, eps=None):
+    def encode(self, row_ids, cond, B, mean=True, x_dense=None, eps=None, covs=None):
         """Eval-mode encoder pass: returns (z or mean [B,Z], mean, var) device tensors (views of the workspace)."""
         L, P = self.lib, self.p
         self._ensure(B)
@@ -797,10 +899,15 @@ class CVAEEngine:
                                              ws["x"].data_ptr(), G, ws["sf"].data_ptr(), st), "csr_gather")
         a = ws["x"].data_ptr()
         cond_p = ptr(cond) if C > 0 else None
+        if self.cond_embed:
+            self._embed_lookup(covs, B, st)
+            cw, cwp, cvec_p, cE = 0, None, ws["cvec"].data_ptr(), self.E
+        else:
+            cw, cwp, cvec_p, cE = C, cond_p, None, 0
         for ly in self.enc:
             sp, S, stride = self._gemm(0, 0, a, ly.n_in, P[ly.w].data_ptr(), ly.n_in, B, ly.n_out, ly.n_in, st)
             _lib.check(L.sca_layer_fwd(sp, S, stride, B, ly.n_out, ptr(P[ly.b]) if ly.b else None,
-                                       ptr(P[ly.wc]) if ly.wc else None, C, cond_p, None, 0, self.norm, 1, 0.0, None,
+                                       ptr(P[ly.wc]) if ly.wc else None, cw, cwp, cvec_p, cE, self.norm, 1, 0.0, None,
                                        self.seed, ly.rng_stream, None, ws[ly.tag + ".yn"].data_ptr(),
                                        ws[ly.tag + ".rs"].data_ptr(), ws[ly.tag + ".h"].data_ptr(), st), "layer_fwd")
             a = ws[ly.tag + ".h"].data_ptr()

@@ -2,5 +2,7 @@ from .trvae.trvae import trVAE
 from .trvae.trvae_model import TRVAE
 from .expimap.expimap import expiMap
 from .expimap.expimap_model import EXPIMAP
+from .scpoli.scpoli import scpoli
+from .scpoli.scpoli_model import scPoli
 
-__all__ = ["trVAE", "TRVAE", "expiMap", "EXPIMAP"]
+__all__ = ["trVAE", "TRVAE", "expiMap", "EXPIMAP", "scpoli", "scPoli"]

@@ -1,4 +1,5 @@
 from .trvae.unsupervised import trVAETrainer
 from .expimap.regularized import expiMapTrainer
+from .scpoli.trainer import scPoliTrainer
 
-__all__ = ["trVAETrainer", "expiMapTrainer"]
+__all__ = ["trVAETrainer", "expiMapTrainer", "scPoliTrainer"]

@@ -89,3 +89,32 @@ def test_prototype_fixtures():
     v.backward()
     assert abs(v.item() - float(z["ll_val"])) <= 1e-6 * float(z["ll_val"])
     assert rel_err(lg.grad.numpy(), z["ll_dlat"]) < 1e-5
+
+
+def test_multi_condition_dataset_matches_reference():
+    """Host logic: MultiConditionAnnotatedDataset encodings / items against the reference's (dataset/scpoli)."""
+    import pandas as pd
+    import scipy.sparse as sp
+    import scarches_amd as sca
+    z = np.load(GOLDEN + "/scpoli_dataset.npz")
+    n, g = z["shape"]
+    xs = sp.csr_matrix((z["x_data"], z["x_indices"], z["x_indptr"]), shape=(n, g))
+    obs = pd.DataFrame({"study": z["study"].astype(str), "tech": z["tech"].astype(str), "ct": z["ct"].astype(str)})
+    obs["conditions_combined"] = obs[["study", "tech"]].apply(lambda r: "_".join(r), axis=1)
+    ad = sca.CellData(xs, obs)
+    enc = {"study": {"s0": 0, "s1": 1, "s2": 2}, "tech": {"a": 0, "b": 1}}
+    comb = {c: i for i, c in enumerate(z["combined_names"].astype(str).tolist())}
+    lab = np.zeros((n, 1))
+    lab[::2] = 1
+    ds = sca.dataset.MultiConditionAnnotatedDataset(ad, ["study", "tech"], enc, comb, ["ct"],
+                                                    {"T": 0, "B": 1, "NK": 2, "unk": -1}, lab)
+    assert np.array_equal(ds.conditions.numpy(), z["conditions"])
+    assert np.array_equal(ds.conditions_combined.numpy(), z["conditions_combined"])
+    assert np.array_equal(ds.cell_types.numpy(), z["cell_types"])
+    assert np.allclose(ds.size_factors.numpy(), z["size_factors"])
+    assert np.array_equal(ds.labeled_vector.numpy(), z["labeled"])
+    item = ds[np.array([0, 5, 7])]
+    assert np.array_equal(item["x"].numpy(), z["item_x"])
+    assert np.array_equal(item["batch"].numpy(), z["item_batch"])
+    assert np.array_equal(item["combined_batch"].numpy(), z["item_combined"])
+    assert np.array_equal(item["celltypes"].numpy(), z["item_celltypes"])
