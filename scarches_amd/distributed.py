@@ -15,15 +15,31 @@ def is_dist() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
-def allreduce_mean_(flat: torch.Tensor, world: int | None = None) -> torch.Tensor:
-    """In-place mean all-reduce of the flat gradient buffer (the whole model is one bucket)."""
+def allreduce_mean_(flat: torch.Tensor, world: int | None = None, weight: float | None = None) -> torch.Tensor:
+    """In-place all-reduce of the flat gradient buffer (the whole model is one bucket).
+
+    Every rank holds the gradient of the MEAN loss over its local cells.  With equal shards the global-batch
+    gradient is the plain mean over ranks; with ragged shards (last partial minibatch) pass
+    weight = n_local / n_global and the weighted sum is exact."""
     if world is None:
         world = dist.get_world_size()
     if world <= 1:
         return flat
+    if weight is not None:
+        flat.mul_(float(weight))
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return flat
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat.mul_(1.0 / world)
     return flat
+
+
+def local_slice(ids: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    """This rank's contiguous slice of a GLOBAL minibatch of row ids (every rank draws the same global sample from
+    the same seed, so the slices are disjoint and cover the minibatch: stratified sampling with replacement keeps
+    its single-device semantics)."""
+    lo, hi = shard_range(ids.numel(), rank, world)
+    return ids[lo:hi]
 
 
 def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:

@@ -148,10 +148,12 @@ class scPoliTrainer(Trainer):
             ids = torch.randperm(n_train, device=self.device, generator=self._gen)[:self.n_samples]
         for lo in range(0, self.n_samples, self.batch_size):
             b = ids[lo:lo + self.batch_size]
+            n_global = b.numel()
             if self.world > 1:
-                s, e = sdist.shard_range(b.numel(), self.rank, self.world)
-                b = b[s:e]
-            yield self._batch(self._train_dev, b)
+                b = sdist.local_slice(b, self.rank, self.world)
+            batch = self._batch(self._train_dev, b)
+            batch["n_global"] = n_global
+            yield batch
 
     # ------------------------------------------------------------------------------------------ loop
     def train(self, n_epochs=400, lr=1e-3, eps=0.01):
@@ -211,9 +213,13 @@ class scPoliTrainer(Trainer):
         eng = self.engine
         eng.begin_step(alpha_kl=self.calc_alpha_coeff(), lr=self.optimizer.param_groups[0]["lr"], eps=self._eps,
                        clip=self.clip_value)
-        self.current_loss = self.loss(batch_data)
+        if batch_data["rows"].numel() > 0:
+            self.current_loss = self.loss(batch_data)
+        else:
+            eng.flat_g.zero_()
         if self.world > 1:
-            sdist.allreduce_mean_(eng.flat_g, self.world)
+            sdist.allreduce_mean_(eng.flat_g, self.world,
+                                  weight=batch_data["rows"].numel() / batch_data["n_global"])
         eng.adam_step(weight_decay=self.weight_decay, wd_overrides=self._wd_over)
 
     # ------------------------------------------------------------------------------------------ prototypes

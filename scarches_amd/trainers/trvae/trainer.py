@@ -127,12 +127,12 @@ class Trainer:
         out = []
         for lo in range(0, self.n_samples, self.batch_size):
             b = ids[lo:lo + self.batch_size]
+            n_global = b.numel()
             if self.world > 1:
-                s, e = sdist.shard_range(b.numel(), self.rank, self.world)
-                b = b[s:e]
+                b = sdist.local_slice(b, self.rank, self.world)
             c = cond_all[b]
             order = torch.argsort(c, stable=True)
-            out.append((b[order].contiguous(), c[order].contiguous()))
+            out.append((b[order].contiguous(), c[order].contiguous(), n_global))
         return out
 
     # ------------------------------------------------------------------------------------------ schedule
@@ -192,9 +192,13 @@ class Trainer:
         eng = self.engine
         eng.begin_step(alpha_kl=self.calc_alpha_coeff(), lr=self.optimizer.param_groups[0]["lr"], eps=self._eps,
                        clip=self.clip_value)
-        self.current_loss = self.loss(batch_data)
+        if batch_data[0].numel() > 0:
+            self.current_loss = self.loss(batch_data)
+        else:                       # a rank whose slice of a tiny last minibatch is empty contributes zeros
+            eng.flat_g.zero_()
         if self.world > 1:
-            sdist.allreduce_mean_(eng.flat_g, self.world)
+            # exact global-minibatch gradient also when the shards are ragged (last partial minibatch)
+            sdist.allreduce_mean_(eng.flat_g, self.world, weight=batch_data[0].numel() / batch_data[2])
         eng.adam_step(weight_decay=self.weight_decay)
 
     def _read_logs(self, prefix):

@@ -11,6 +11,6 @@ class trVAETrainer(Trainer):
         super().__init__(model, adata, **kwargs)
 
     def loss(self, total_batch=None):
-        row_ids, cond = total_batch
+        row_ids, cond = total_batch[0], total_batch[1]
         # engine.losses = [recon, kl, mmd, recon + alpha*kl + mmd]; gradients land in engine.flat_g
         return self.engine.forward_backward(row_ids, cond, row_ids.numel(), train=True, compute_grad=True)
