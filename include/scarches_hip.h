@@ -117,6 +117,21 @@ int sca_adam_step(float* p, const float* g, float* m, float* v, long long n, con
 int sca_finalize_losses(const float* row_recon, float recon_sign, const float* row_kl, int B, const double* mmd_part,
                         int n_part, const float* hyper, float* losses, double* accum, void* stream);
 
+/* ---- BatchNorm1d variant of the layer block (use_bn=True) -------------------------------------------------------
+ * nn.BatchNorm1d(affine=True) between Linear and ReLU (models/trvae/modules.py:79,146,161).  sca_bn_fwd takes the
+ * pre-activation a [B][H] (sca_layer_fwd with norm=0, relu=0), overwrites it with xhat and writes
+ * h = dropout(relu(xhat*gamma + beta)); use_batch_stats=1: biased batch statistics (train mode) and, with
+ * update_running, running <- (1-momentum) running + momentum * (mean, unbiased var); use_batch_stats=0: running
+ * statistics (eval mode).  stats [2][H] = (mean, rstd) is kept for backward; acc: scratch of 2*H doubles.
+ * sca_bn_bwd: da = d loss / d a, dgamma, dbeta (either may be NULL) from the upstream slabs dh (+ extra). */
+int sca_bn_fwd(float* a, int B, int H, const float* gamma, const float* beta, float* running_mean, float* running_var,
+               int use_batch_stats, int update_running, float momentum, float p, const uint8_t* mask, uint64_t seed,
+               uint32_t rng_stream, const uint32_t* step, double* acc, float* stats, float* h, void* stream);
+int sca_bn_bwd(const float* dh, int S, long long slab_stride, const float* extra, int B, int H, const float* xhat,
+               const float* stats, const float* gamma, const float* beta, int batch_stats, float p,
+               const uint8_t* mask, uint64_t seed, uint32_t rng_stream, const uint32_t* step, double* acc, float* da,
+               float* dgamma, float* dbeta, void* stream);
+
 /* ---- expiMap ---------------------------------------------------------------------------------------------------
  * sca_masked_copy: dst[r*ldd+c] = src[r*lds+c] * (mask ? mask[r*ldm+c] : 1).  Packs MaskedLinear weights
  * (weight*mask, models/expimap/modules.py:24-25) of expr_L / ext_L_m / ext_L into ONE decoder matrix

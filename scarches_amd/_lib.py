@@ -48,6 +48,8 @@ SIGNATURES = {
     "sca_prox_group_lasso": [P, I, I, F, P, P],
     "sca_hsic_workspace_floats": [I],
     "sca_hsic_fwd_bwd": [P, I, I, I, P, F, F, F, P, P, P, I, P, I, P],
+    "sca_bn_fwd": [P, I, I, P, P, P, P, I, I, F, F, P, U64, U32, P, P, P, P, P],
+    "sca_bn_bwd": [P, I, LL, P, I, I, P, P, P, P, I, F, P, U64, U32, P, P, P, P, P, P],
     "sca_embed_lookup": [P, I, I, P, I, I, F, P, P, I, P],
     "sca_embed_scatter_add": [P, P, I, I, I, I, P, I, P, P],
     "sca_proto_workspace_bytes": [I, I, I],

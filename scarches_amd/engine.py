@@ -27,11 +27,12 @@ def _round_up(n, a):
 
 
 class _Layer:
-    __slots__ = ("tag", "w", "b", "wc", "n_in", "n_out", "rng_stream", "mask_key")
+    __slots__ = ("tag", "w", "b", "wc", "n_in", "n_out", "rng_stream", "mask_key", "bn")
 
-    def __init__(self, tag, w, b, wc, n_in, n_out, rng_stream, mask_key):
+    def __init__(self, tag, w, b, wc, n_in, n_out, rng_stream, mask_key, bn=None):
         self.tag, self.w, self.b, self.wc = tag, w, b, wc
         self.n_in, self.n_out, self.rng_stream, self.mask_key = n_in, n_out, rng_stream, mask_key
+        self.bn = bn        # state-dict prefix of the BatchNorm1d after this Linear (use_bn), e.g. "encoder.FC.N0"
 
 
 class CVAEEngine:
@@ -48,9 +49,9 @@ class CVAEEngine:
         self.G, self.C, self.H, self.Z = int(s["G"]), int(s["C"]), list(s["H"]), int(s["Z"])
         self.recon = s["recon"]
         self.use_bn, self.use_ln = bool(s.get("use_bn", False)), bool(s.get("use_ln", True))
-        if self.use_bn:
-            raise NotImplementedError("use_bn=True (BatchNorm1d) is not built yet in the HIP path; use use_ln")
-        self.norm = 1 if self.use_ln else 0
+        # BatchNorm takes precedence over LayerNorm, as in the reference (modules.py:78-81)
+        self.norm = 1 if (self.use_ln and not self.use_bn) else 0
+        self.freeze = bool(s.get("freeze", False))
         self.dr_rate = float(s.get("dr_rate", 0.0))
         self.use_mmd = bool(s.get("use_mmd", False))
         self.mmd_on = s.get("mmd_on", "z")
@@ -173,6 +174,24 @@ class CVAEEngine:
                 self.out_w, self.out_b = "decoder.recon_decoder.0.weight", "decoder.recon_decoder.0.bias"
             else:
                 self.out_w, self.out_b = "decoder.mean_decoder.0.weight", "decoder.mean_decoder.0.bias"
+        # BatchNorm1d(affine) after every hidden Linear when use_bn: parameters <prefix>.weight/.bias live in the flat
+        # buffer, the running statistics are buffers handed in through spec["buffers"] (updated in place)
+        self.buffers: Dict[str, torch.Tensor] = {}
+        if self.use_bn:
+            for i, ly in enumerate(self.enc):
+                ly.bn = f"encoder.FC.N{i}"
+            for i, ly in enumerate(self.dec):
+                ly.bn = "decoder.FirstL.N0" if i == 0 else f"decoder.HiddenL.N{i}"
+            given = s.get("buffers") or {}
+            for ly in self.enc + self.dec:
+                for suffix, init in (("running_mean", 0.0), ("running_var", 1.0)):
+                    k = f"{ly.bn}.{suffix}"
+                    t = given.get(k)
+                    t = torch.full((ly.n_out,), init) if t is None else t.detach()
+                    self.buffers[k] = t.to(dev, torch.float32).contiguous().clone()
+                k = f"{ly.bn}.num_batches_tracked"
+                t = given.get(k)
+                self.buffers[k] = (torch.zeros((), dtype=torch.long) if t is None else t.detach()).to(dev).clone()
         Zt = self.Zt
         ow, ob = self.offsets[fused_w[0]], self.offsets[fused_b[0]]
         self.heads_w = self.flat_p[ow:ow + 2 * Zt * H[-1]].view(2 * Zt, H[-1])
@@ -251,6 +270,10 @@ class CVAEEngine:
             ws[ly.tag + ".yn"] = torch.empty(B, ly.n_out, dtype=f32, device=dev)
             ws[ly.tag + ".rs"] = torch.empty(B, dtype=f32, device=dev)
             ws[ly.tag + ".h"] = torch.empty(B, ly.n_out, dtype=f32, device=dev)
+        if self.use_bn:
+            ws["bn_acc"] = torch.zeros(2 * Hmax, dtype=torch.float64, device=dev)
+            for ly in self.enc + self.dec:
+                ws[ly.tag + ".bnstats"] = torch.empty(2, ly.n_out, dtype=f32, device=dev)
         ws["mu_lv"] = torch.empty(B, 2 * Z, dtype=f32, device=dev)
         ws["eps"] = torch.empty(B, Z, dtype=f32, device=dev)
         ws["z"] = torch.empty(B, Z, dtype=f32, device=dev)
@@ -377,6 +400,35 @@ class CVAEEngine:
         if p != dst.data_ptr():
             _lib.check(L.sca_splitk_reduce(p, S, stride, dst.data_ptr(), M * N, st), "splitk_reduce")
 
+    def _layer_block_fwd(self, ly, sp, S, stride, B, cond_args, p_drop, mask_ptr, train, step_p, st):
+        """Everything between two GEMMs of one layer: slab sum + bias + condition term, then LayerNorm or BatchNorm,
+        ReLU, dropout.  Leaves the normalised pre-activation in ws[tag.yn] and the output in ws[tag.h]."""
+        L, P, ws = self.lib, self.p, self.ws
+        ptr = _lib.ptr
+        cw, cwp, cvec_p, cE = cond_args
+        yn, h = ws[ly.tag + ".yn"].data_ptr(), ws[ly.tag + ".h"].data_ptr()
+        if ly.bn is None:
+            _lib.check(L.sca_layer_fwd(sp, S, stride, B, ly.n_out, ptr(P[ly.b]) if ly.b else None,
+                                       ptr(P[ly.wc]) if ly.wc else None, cw, cwp, cvec_p, cE, self.norm, 1, p_drop,
+                                       mask_ptr, self.seed, ly.rng_stream, step_p, yn,
+                                       ws[ly.tag + ".rs"].data_ptr(), h, st), "layer_fwd")
+            return h
+        # BatchNorm: pre-activation first (row kernel without norm / activation), then the batch-wise part
+        _lib.check(L.sca_layer_fwd(sp, S, stride, B, ly.n_out, ptr(P[ly.b]) if ly.b else None,
+                                   ptr(P[ly.wc]) if ly.wc else None, cw, cwp, cvec_p, cE, 0, 0, 0.0, None,
+                                   self.seed, ly.rng_stream, None, yn, None, yn, st), "layer_pre")
+        bw = ly.bn + ".weight"
+        # frozen surgery models stop tracking running statistics (trainers/trvae/trainer.py:264-270)
+        update = bool(train) and not (self.freeze and not self.trainable[bw])
+        _lib.check(L.sca_bn_fwd(yn, B, ly.n_out, P[bw].data_ptr(), P[ly.bn + ".bias"].data_ptr(),
+                                self.buffers[ly.bn + ".running_mean"].data_ptr(),
+                                self.buffers[ly.bn + ".running_var"].data_ptr(), int(bool(train)), int(update), 0.1,
+                                p_drop, mask_ptr, self.seed, ly.rng_stream, step_p, ws["bn_acc"].data_ptr(),
+                                ws[ly.tag + ".bnstats"].data_ptr(), h, st), "bn_fwd")
+        if update:
+            self.buffers[ly.bn + ".num_batches_tracked"] += 1
+        return h
+
     # ------------------------------------------------------------------------------------------ the step
     def forward_backward(self, row_ids: Optional[torch.Tensor], cond: Optional[torch.Tensor], B: int, train=True,
                          compute_grad=True, eps: Optional[torch.Tensor] = None,
@@ -416,14 +468,12 @@ class CVAEEngine:
         else:
             cw, cwp, cvec_p, cE = C, cond_p, None, 0
 
+        cond_args = (cw, cwp, cvec_p, cE)
+
         def layer_forward(ly, a_in):
             sp, S, stride = self._gemm(0, 0, a_in, ly.n_in, P[ly.w].data_ptr(), ly.n_in, B, ly.n_out, ly.n_in, st)
-            m = masks.get(ly.mask_key)
-            _lib.check(L.sca_layer_fwd(sp, S, stride, B, ly.n_out, ptr(P[ly.b]) if ly.b else None,
-                                       ptr(P[ly.wc]) if ly.wc else None, cw, cwp, cvec_p, cE, self.norm, 1, p_drop,
-                                       ptr(m), self.seed, ly.rng_stream, step_p, ws[ly.tag + ".yn"].data_ptr(),
-                                       ws[ly.tag + ".rs"].data_ptr(), ws[ly.tag + ".h"].data_ptr(), st), "layer_fwd")
-            return ws[ly.tag + ".h"].data_ptr()
+            return self._layer_block_fwd(ly, sp, S, stride, B, cond_args, p_drop, ptr(masks.get(ly.mask_key)), train,
+                                         step_p, st)
 
         # 2. encoder
         a = ws["x"].data_ptr()
@@ -568,9 +618,17 @@ class CVAEEngine:
         AUX = "slab_aux" if self.overlap else "slab"
         m = masks.get(ly.mask_key)
         da = ws[ly.tag + ".da"].data_ptr()
-        _lib.check(L.sca_layer_bwd(sp, S, stride, extra, B, ly.n_out, ws[ly.tag + ".yn"].data_ptr(),
-                                   ws[ly.tag + ".rs"].data_ptr(), self.norm, 1, p_drop, ptr(m), self.seed,
-                                   ly.rng_stream, self.step_ctr.data_ptr(), da, st), "layer_bwd")
+        if ly.bn is None:
+            _lib.check(L.sca_layer_bwd(sp, S, stride, extra, B, ly.n_out, ws[ly.tag + ".yn"].data_ptr(),
+                                       ws[ly.tag + ".rs"].data_ptr(), self.norm, 1, p_drop, ptr(m), self.seed,
+                                       ly.rng_stream, self.step_ctr.data_ptr(), da, st), "layer_bwd")
+        else:
+            bw, bb = ly.bn + ".weight", ly.bn + ".bias"
+            _lib.check(L.sca_bn_bwd(sp, S, stride, extra, B, ly.n_out, ws[ly.tag + ".yn"].data_ptr(),
+                                    ws[ly.tag + ".bnstats"].data_ptr(), P[bw].data_ptr(), P[bb].data_ptr(), 1, p_drop,
+                                    ptr(m), self.seed, ly.rng_stream, self.step_ctr.data_ptr(),
+                                    ws["bn_acc"].data_ptr(), da, Gd[bw].data_ptr() if T[bw] else None,
+                                    Gd[bb].data_ptr() if T[bb] else None, st), "bn_bwd")
         need_w = T[ly.w]
         need_b = bool(ly.b) and T[ly.b]
         need_c = bool(ly.wc) and T[ly.wc]
@@ -906,11 +964,7 @@ class CVAEEngine:
             cw, cwp, cvec_p, cE = C, cond_p, None, 0
         for ly in self.enc:
             sp, S, stride = self._gemm(0, 0, a, ly.n_in, P[ly.w].data_ptr(), ly.n_in, B, ly.n_out, ly.n_in, st)
-            _lib.check(L.sca_layer_fwd(sp, S, stride, B, ly.n_out, ptr(P[ly.b]) if ly.b else None,
-                                       ptr(P[ly.wc]) if ly.wc else None, cw, cwp, cvec_p, cE, self.norm, 1, 0.0, None,
-                                       self.seed, ly.rng_stream, None, ws[ly.tag + ".yn"].data_ptr(),
-                                       ws[ly.tag + ".rs"].data_ptr(), ws[ly.tag + ".h"].data_ptr(), st), "layer_fwd")
-            a = ws[ly.tag + ".h"].data_ptr()
+            a = self._layer_block_fwd(ly, sp, S, stride, B, (cw, cwp, cvec_p, cE), 0.0, None, False, None, st)
         Hl = self.H[-1]
         sp, S, stride = self._gemm(0, 0, a, Hl, self.heads_w.data_ptr(), Hl, B, 2 * Z, Hl, st)
         self.step_ctr += 1          # fresh noise for every sampled pass
@@ -930,8 +984,6 @@ class CVAEEngine:
         ptr = _lib.ptr
         sp, S, stride = self._gemm(0, 0, ws["z"].data_ptr(), ly.n_in, P[ly.w].data_ptr(), ly.n_in, B, ly.n_out,
                                    ly.n_in, st)
-        _lib.check(L.sca_layer_fwd(sp, S, stride, B, ly.n_out, None, ptr(P[ly.wc]) if ly.wc else None, self.C,
-                                   ptr(cond) if self.C > 0 else None, None, 0, self.norm, 1, 0.0, None, self.seed,
-                                   ly.rng_stream, None, ws[ly.tag + ".yn"].data_ptr(), ws[ly.tag + ".rs"].data_ptr(),
-                                   ws[ly.tag + ".h"].data_ptr(), st), "layer_fwd")
+        self._layer_block_fwd(ly, sp, S, stride, B, (self.C, ptr(cond) if self.C > 0 else None, None, 0), 0.0, None,
+                              False, None, st)
         return ws[ly.tag + ".h"][:B]

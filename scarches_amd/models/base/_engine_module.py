@@ -28,15 +28,22 @@ class EngineBackedModule(torch.nn.Module):
                 p = next(self.parameters())
                 device = p.device if p.device.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
             named = OrderedDict((k, p.detach()) for k, p in self.named_parameters())
-            eng = CVAEEngine(self._spec(), named, device)
+            spec = dict(self._spec())
+            spec["buffers"] = {k: b for k, b in self.named_buffers()}       # BatchNorm running statistics
+            spec["freeze"] = bool(getattr(self, "freeze", False))
+            eng = CVAEEngine(spec, named, device)
             for k, p in self.named_parameters():
                 p.data = eng.p[k]
+            for k, b in self.named_buffers():       # running statistics are updated in place by the engine
+                if k in eng.buffers:
+                    b.data = eng.buffers[k]
             self._engine = eng
         self._sync_engine_flags()
         return self._engine
 
     def _sync_engine_flags(self):
         self._engine.set_trainable([k for k, p in self.named_parameters() if p.requires_grad])
+        self._engine.freeze = bool(getattr(self, "freeze", False))
 
     def _apply(self, fn, *args, **kwargs):
         # .cuda() / .to(device): moving would detach the parameters from the flat buffer, so rebuild the engine lazily

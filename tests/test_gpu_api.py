@@ -167,3 +167,34 @@ def test_module_forward_api():
     assert z.shape == (12, 5)
     with pytest.raises(Exception):
         trVAE(50, ["a"], [32], 5, recon_loss="poisson")
+
+
+def test_batchnorm_model_trains_and_freezes_running_stats(tmp_path):
+    """use_bn=True: running statistics move during reference training, are saved / loaded with the state dict, and
+    stay put during frozen query training (trainers/trvae/trainer.py:264-270)."""
+    from scarches_amd.anndata_lite import CellData
+    from scarches_amd.models import TRVAE
+    X, obs = synth(900, 96, 3, 4, seed=11)
+    is_q = (obs["study"] == "s2").to_numpy()
+    ad, adq = CellData(X[~is_q], obs[~is_q]), CellData(X[is_q], obs[is_q])
+    with contextlib.redirect_stdout(io.StringIO()):
+        torch.manual_seed(0)
+        m = TRVAE(ad, condition_key="study", hidden_layer_sizes=[32], latent_dim=6, use_bn=True, use_ln=False,
+                  recon_loss="zinb", use_mmd=False)
+        m.train(n_epochs=8, batch_size=128, alpha_epoch_anneal=5, use_early_stopping=False, monitor=False)
+    sd = m.model.state_dict()
+    assert float(sd["encoder.FC.N0.running_mean"].abs().max()) > 0
+    assert int(sd["encoder.FC.N0.num_batches_tracked"]) > 0
+    logs = m.trainer.logs
+    assert logs["epoch_recon_loss"][-1] < logs["epoch_recon_loss"][0]
+    lat = m.get_latent(mean=True)
+    assert np.isfinite(lat).all()
+    m.save(str(tmp_path / "bn"), overwrite=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m2 = TRVAE.load(str(tmp_path / "bn"), ad)
+        assert np.allclose(m2.get_latent(mean=True), lat, rtol=1e-5, atol=1e-6)
+        q = TRVAE.load_query_data(adq, m)
+        rm0 = q.model.state_dict()["encoder.FC.N0.running_mean"].cpu().clone()
+        q.train(n_epochs=3, batch_size=128, use_early_stopping=False, monitor=False, weight_decay=0)
+    assert torch.equal(q.model.state_dict()["encoder.FC.N0.running_mean"].cpu(), rm0)
+    assert np.isfinite(q.get_latent(mean=True)).all()

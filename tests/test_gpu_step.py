@@ -10,7 +10,7 @@ from tests._util import TRVAE_CASES, grads_close, load_case, rel_err
 
 pytestmark = pytest.mark.gpu
 
-LN_CASES = [c for c in TRVAE_CASES if c != "trvae_zinb_bn"]      # BatchNorm is not built yet
+LN_CASES = TRVAE_CASES            # includes the BatchNorm case trvae_zinb_bn
 BUFFERS = ("running_mean", "running_var", "num_batches_tracked")
 
 
@@ -19,6 +19,7 @@ def make_engine(name):
     z, cfg, W, Gr, masks = load_case(name)
     spec = dict(cfg)
     params = OrderedDict((k, torch.tensor(v)) for k, v in W.items() if not k.endswith(BUFFERS))
+    spec["buffers"] = {k: torch.tensor(v) for k, v in W.items() if k.endswith(BUFFERS)}
     eng = CVAEEngine(spec, params, "cuda")
     eng.bind_csr(torch.tensor(z["x_indptr"]).cuda(), torch.tensor(z["x_indices"]).cuda(),
                  torch.tensor(z["x_data"]).cuda())
@@ -77,6 +78,22 @@ def test_adam_steps_match_reference(name):
         ref = z["adam/" + k]
         err = np.max(np.abs(eng.p[k].cpu().numpy() - ref))
         assert err <= 3e-6 * max(1.0, np.max(np.abs(ref))), (k, err)
+
+
+def test_batchnorm_running_stats_and_eval_latent():
+    """BatchNorm: one train-mode forward moves the running statistics like the reference's; the eval-mode latent
+    (running statistics) then matches the reference's get_latent."""
+    eng, z, cfg, W, Gr, masks = make_engine("trvae_zinb_bn")
+    run_step(eng, z, cfg, masks, float(z["alpha"]))
+    for k in [f for f in z.files if f.startswith("bn_after/")]:
+        name = k[len("bn_after/"):]
+        assert rel_err(eng.buffers[name].cpu().numpy(), z[k]) < 1e-5, name
+    assert int(eng.buffers["encoder.FC.N0.num_batches_tracked"]) == 1
+    cond = torch.tensor(z["batch"]).to(torch.int32).cuda()
+    zz, mu, var = eng.encode(None, cond, cfg["B"], mean=True)
+    torch.cuda.synchronize()
+    assert rel_err(mu.cpu().numpy(), z["z_mean"]) < 1e-5
+    assert rel_err(var.cpu().numpy(), z["z_var"]) < 1e-5
 
 
 def test_eval_latent_matches_reference():
