@@ -36,8 +36,8 @@ def parse():
     ap.add_argument("--latent", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
-    ap.add_argument("--launch", choices=["auto", "graph", "eager"], default="auto",
-                    help="HIP-graph replay, eager launches, or auto (graphs for B <= 2048)")
+    ap.add_argument("--launch", choices=["auto", "plan", "graph", "eager"], default="auto",
+                    help="recorded launch plan, HIP-graph replay, eager launches, or auto (= graph)")
     return ap.parse_args()
 
 
@@ -151,7 +151,7 @@ def main():
         def one(i):
             # gather -> fwd -> bwd -> (RCCL gradient all-reduce) -> Adam; see --launch
             eng.train_step(ids[i], cs[i], Bx, alpha_kl=0.5, lr=1e-3, eps=0.01, clip=0.0, weight_decay=0.04,
-                           world=world, use_graph={"auto": "auto", "graph": True, "eager": False}[a.launch])
+                           world=world, use_graph={"auto": "auto", "plan": "plan", "graph": True, "eager": False}[a.launch])
         for i in range(warmup):
             one(i)
         if world > 1:

@@ -114,8 +114,34 @@ int sca_mmd_fwd_bwd(const float* feat, int ld, const int32_t* cond, int B, int D
  * (trainers/trvae/unsupervised.py:62-70); accum[0..3] += those, accum[4] += 1 (per-epoch log means without syncs). */
 int sca_adam_step(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1,
                   float beta2, float weight_decay, void* stream);
+/* sca_begin_step: hyper[0..5] <- the per-step scalars (values of trainer.py:193-209 annealing, param_groups lr, Adam
+ * bias corrections for step t), step_ctr += 1 (Philox stream of this step's dropout / z noise).
+ * sca_fill_zero: zero `bytes` bytes (optimizer.zero_grad() for the accumulating gradient targets). */
+int sca_begin_step(float* hyper, uint32_t* step_ctr, float alpha_kl, float lr, float bias_corr1,
+                   float bias_corr2_sqrt, float eps, float clip, void* stream);
+int sca_fill_zero(void* p, long long bytes, void* stream);
 int sca_finalize_losses(const float* row_recon, float recon_sign, const float* row_kl, int B, const double* mmd_part,
                         int n_part, const float* hyper, float* losses, double* accum, void* stream);
+
+/* ---- gradient tail ---------------------------------------------------------------------------------------------
+ * Every batch reduction that only feeds Adam, as jobs of ONE launch: kind 0 sums the split-K slabs of a weight-gradient
+ * GEMM (as sca_splitk_reduce), kind 1 is the column reduction of sca_cond_colsum (db[h] = sum_b da[b][h], dWc[h][c] =
+ * sum over rows with cond == c; autograd of the bias broadcast / one-hot GEMM of CondLayers, modules.py:21-27).
+ * `jobs` is a HOST array (copied into the kernel arguments); at most sca_grad_tail_max_jobs() jobs, C <= 512.
+ * For B > 1024 the kind-1 targets (db, dWc) are accumulated with atomics and must be zeroed by the caller. */
+typedef struct {
+    int32_t kind;          /* 0: dst[i] = sum_s src[s*stride + i], i < n;  1: column sums of da [B][H] */
+    int32_t S;
+    long long stride;
+    const float* src;      /* kind 0: slabs; kind 1: da */
+    float* dst;            /* kind 0: destination; kind 1: db [H] or NULL */
+    long long n;
+    float* dWc;            /* kind 1: [H][C] or NULL */
+    const int32_t* cond;   /* kind 1: [B] (with dWc) */
+    int32_t B, H, C, pad;
+} sca_tail_job;
+int sca_grad_tail_max_jobs(void);
+int sca_grad_tail(const sca_tail_job* jobs, int n_jobs, void* stream);
 
 /* ---- BatchNorm1d variant of the layer block (use_bn=True) -------------------------------------------------------
  * nn.BatchNorm1d(affine=True) between Linear and ReLU (models/trvae/modules.py:79,146,161).  sca_bn_fwd takes the

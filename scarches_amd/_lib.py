@@ -19,6 +19,13 @@ F = C.c_float
 U64 = C.c_uint64
 U32 = C.c_uint32
 
+class TailJob(C.Structure):
+    """sca_tail_job of include/scarches_hip.h."""
+    _fields_ = [("kind", C.c_int32), ("S", C.c_int32), ("stride", C.c_longlong), ("src", C.c_void_p),
+                ("dst", C.c_void_p), ("n", C.c_longlong), ("dWc", C.c_void_p), ("cond", C.c_void_p),
+                ("B", C.c_int32), ("H", C.c_int32), ("C", C.c_int32), ("pad", C.c_int32)]
+
+
 # name -> argtypes (restype is always int); mirrors include/scarches_hip.h one to one
 SIGNATURES = {
     "sca_abi_version": [],
@@ -43,11 +50,15 @@ SIGNATURES = {
     "sca_mmd_fwd_bwd": [P, I, P, I, I, I, I, F, P, P, P, P, LL, P],
     "sca_adam_step": [P, P, P, P, LL, P, F, F, F, P],
     "sca_finalize_losses": [P, F, P, I, P, I, P, P, P, P],
+    "sca_begin_step": [P, P, F, F, F, F, F, F, P],
+    "sca_fill_zero": [P, LL, P],
     "sca_masked_copy": [P, I, P, I, P, I, I, I, P],
     "sca_prox_l1": [P, LL, F, P, P],
     "sca_prox_group_lasso": [P, I, I, F, P, P],
     "sca_hsic_workspace_floats": [I],
     "sca_hsic_fwd_bwd": [P, I, I, I, P, F, F, F, P, P, P, I, P, I, P],
+    "sca_grad_tail_max_jobs": [],
+    "sca_grad_tail": [P, I, P],
     "sca_bn_fwd": [P, I, I, P, P, P, P, I, I, F, F, P, U64, U32, P, P, P, P, P],
     "sca_bn_bwd": [P, I, LL, P, I, I, P, P, P, P, I, F, P, U64, U32, P, P, P, P, P, P],
     "sca_embed_lookup": [P, I, I, P, I, I, F, P, P, I, P],

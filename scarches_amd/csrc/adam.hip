@@ -60,7 +60,30 @@ __global__ __launch_bounds__(256) void finalize_losses_kernel(const float* __res
     }
 }
 
+// Start of an optimisation step: hyper[0..5] <- (alpha_kl, lr, 1-beta1^t, sqrt(1-beta2^t), eps, clip), step_ctr += 1.
+__global__ void begin_step_kernel(float* __restrict__ hyper, uint32_t* __restrict__ step_ctr, float a, float lr,
+                                  float bc1, float bc2s, float eps, float clip) {
+    if (threadIdx.x == 0) {
+        hyper[0] = a; hyper[1] = lr; hyper[2] = bc1; hyper[3] = bc2s; hyper[4] = eps; hyper[5] = clip;
+        if (step_ctr) step_ctr[0] += 1u;
+    }
+}
+
 }  // namespace
+
+extern "C" int sca_begin_step(float* hyper, uint32_t* step_ctr, float alpha_kl, float lr, float bias_corr1,
+                              float bias_corr2_sqrt, float eps, float clip, void* stream) {
+    hipLaunchKernelGGL(begin_step_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, hyper, step_ctr, alpha_kl, lr,
+                       bias_corr1, bias_corr2_sqrt, eps, clip);
+    SCA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sca_fill_zero(void* p, long long bytes, void* stream) {
+    if (bytes <= 0) return 0;
+    hipError_t e = hipMemsetAsync(p, 0, (size_t)bytes, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : (int)e;
+}
 
 extern "C" int sca_adam_step(float* p, const float* g, float* m, float* v, long long n, const float* hyper,
                              float beta1, float beta2, float weight_decay, void* stream) {

@@ -35,11 +35,36 @@ class _Layer:
         self.bn = bn        # state-dict prefix of the BatchNorm1d after this Linear (use_bn), e.g. "encoder.FC.N0"
 
 
+_QUERIES = {"sca_gemm_splitk_heuristic", "sca_mmd_num_slabs", "sca_mmd_num_partials", "sca_hsic_workspace_floats",
+            "sca_proto_workspace_bytes", "sca_abi_version", "sca_device_name"}
+
+
+class _RecordingLib:
+    """The C ABI as seen by the engine: every launch goes straight to libscarches_hip.so and, while the engine records
+    a launch plan (CVAEEngine.train_step), is also appended to it as (function, argument tuple)."""
+
+    def __init__(self, lib, eng):
+        self._lib, self._eng = lib, eng
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name not in _QUERIES:
+            raw, eng = fn, self._eng
+
+            def fn(*args):
+                if eng._rec is not None:
+                    eng._rec.append((raw, args, True))
+                return raw(*args)
+        setattr(self, name, fn)
+        return fn
+
+
 class CVAEEngine:
     """Forward / backward / Adam of a trVAE-style conditional VAE on one MI355X."""
 
     def __init__(self, spec: dict, named_params: "OrderedDict[str, torch.Tensor]", device):
-        self.lib = _lib.load()
+        self._rec = None
+        self.lib = _RecordingLib(_lib.load(), self)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.HipLibraryError("scarches_amd runs on a HIP device only (no CPU fallback)")
@@ -215,8 +240,10 @@ class CVAEEngine:
         self.Bcap = 0
         # side stream: MMD runs beside the decoder, every dW / bias / condition-weight gradient beside the dX chain
         self.aux = torch.cuda.Stream(device=self.device)
-        self._events = [torch.cuda.Event() for _ in range(32)]
+        self._events = [torch.cuda.Event() for _ in range(64)]
         self._ev_i = 0
+        self._aux_q = []
+        self._rec = None                # launch-plan recorder (train_step)
         self.overlap = True
         self.set_hyper(alpha_kl=1.0, lr=1e-3, eps=0.01, clip=0.0)
 
@@ -341,7 +368,7 @@ class CVAEEngine:
         self._mmd_ns = L.sca_mmd_num_slabs(B, Dm)
         ws["mmd_g"] = torch.empty(max(1, self._mmd_ns) * B * Dm, dtype=f32, device=dev)
         ws["mmd_part"] = torch.zeros(max(1, L.sca_mmd_num_partials(B, Dm)), dtype=torch.float64, device=dev)
-        ws["mmd_extra"] = torch.empty(B, Dm, dtype=f32, device=dev)
+        ws["mmd_g1"] = torch.empty(B, Dm, dtype=f32, device=dev)
         self._sbh = torch.empty(B * Hmax, dtype=f32, device=dev)
         ws["Wt"] = torch.empty(C * C, dtype=f32, device=dev)
         ws["counts"] = torch.empty(C, dtype=torch.int32, device=dev)
@@ -349,24 +376,64 @@ class CVAEEngine:
         self.Bcap = B
 
     # ------------------------------------------------------------------------------------------ helpers
+    def _next_event(self):
+        ev = self._events[self._ev_i]
+        self._ev_i = (self._ev_i + 1) % len(self._events)
+        return ev
+
     def _fork(self):
         """aux stream waits for everything enqueued on the main stream so far."""
         if not self.overlap:
             return torch.cuda.current_stream(self.device).cuda_stream
-        ev = self._events[self._ev_i]
-        self._ev_i = (self._ev_i + 1) % len(self._events)
-        ev.record(torch.cuda.current_stream(self.device))
-        self.aux.wait_event(ev)
+        ev = self._next_event()
+        self._call(ev.record, torch.cuda.current_stream(self.device))
+        self._call(self.aux.wait_event, ev)
         return self.aux.cuda_stream
 
     def _join(self):
         """main stream waits for everything enqueued on the aux stream so far."""
         if not self.overlap:
             return
-        ev = self._events[self._ev_i]
-        self._ev_i = (self._ev_i + 1) % len(self._events)
-        ev.record(self.aux)
-        torch.cuda.current_stream(self.device).wait_event(ev)
+        ev = self._next_event()
+        self._call(ev.record, self.aux)
+        self._call(torch.cuda.current_stream(self.device).wait_event, ev)
+
+    def _call(self, fn, *args):
+        """Run a host-side stream operation now and, while a launch plan is being recorded, remember it."""
+        if self._rec is not None:
+            self._rec.append((fn, args, False))
+        return fn(*args)
+
+    def _defer(self, fn):
+        """Side work for the aux stream that depends on everything enqueued on the main stream so far.  The
+        dependency point (an event) is taken now, the launches are issued at the next _flush(): the host keeps
+        feeding the critical main-stream chain first, the aux stream fills in behind it."""
+        if not self.overlap:
+            fn(torch.cuda.current_stream(self.device).cuda_stream)
+            return
+        ev = self._next_event()
+        self._call(ev.record, torch.cuda.current_stream(self.device))
+        self._aux_q.append((ev, fn))
+
+    def _flush(self):
+        """Issue the deferred aux-stream work; returns an event marking its end on the aux stream."""
+        if not self.overlap:
+            return None
+        for ev, fn in self._aux_q:
+            self._call(self.aux.wait_event, ev)
+            fn(self.aux.cuda_stream)
+        self._aux_q = []
+        ev = self._next_event()
+        self._call(ev.record, self.aux)
+        return ev
+
+    def _wait(self, ev):
+        """main stream waits for an aux-stream event returned by _flush()."""
+        if ev is not None:
+            self._call(torch.cuda.current_stream(self.device).wait_event, ev)
+
+    def _zero(self, t, st):
+        _lib.check(self.lib.sca_fill_zero(t.data_ptr(), t.numel() * t.element_size(), st), "fill_zero")
 
     def _gemm(self, am, bm, A, lda, Bm, ldb, M, N, K, st, out=None, ldc=None, bias=None, force_s1=False,
               slab_key="slab"):
@@ -400,6 +467,56 @@ class CVAEEngine:
         if p != dst.data_ptr():
             _lib.check(L.sca_splitk_reduce(p, S, stride, dst.data_ptr(), M * N, st), "splitk_reduce")
 
+    # ---- gradient tail: slab sums and column reductions that only feed Adam, batched into one launch ------------
+    def _grad_gemm(self, am, bm, A, lda, Bm, ldb, M, N, K, st, dst):
+        """Weight-gradient GEMM into `dst` [M, N]: split-K slabs go to a region of their own and their sum becomes a
+        job of the tail kernel (instead of a sca_splitk_reduce launch per tensor)."""
+        L = self.lib
+        S = L.sca_gemm_splitk_heuristic(M, N, K)
+        if S == 1:
+            _lib.check(L.sca_gemm_f32(am, bm, A, lda, Bm, ldb, dst.data_ptr(), N, M, N, K, 1, 0, None, st), "gemm")
+            return
+        key = "gslab:%d" % dst.data_ptr()
+        slab = self.ws.get(key)
+        if slab is None or slab.numel() < S * M * N:
+            slab = self.ws[key] = torch.empty(S * M * N, dtype=torch.float32, device=self.device)
+        _lib.check(L.sca_gemm_f32(am, bm, A, lda, Bm, ldb, slab.data_ptr(), N, M, N, K, S, M * N, None, st), "gemm")
+        self._tail_jobs.append((0, S, M * N, slab.data_ptr(), dst.data_ptr(), M * N, 0, 0, 0, 0, 0))
+
+    def _colsum(self, da, B, H, cond_p, C, dWc, db, st):
+        """db[h] = sum_b da[b][h]; dWc[h][c] = sum over rows of condition c (tail job; direct launch for huge C)."""
+        if dWc is None and db is None:
+            return
+        if dWc is not None and C > 512:
+            _lib.check(self.lib.sca_cond_colsum(da, B, H, cond_p, C, self.ws["segT"].data_ptr(), dWc, db, st),
+                       "cond_colsum")
+            return
+        self._tail_jobs.append((1, 0, 0, da, db or 0, 0, dWc or 0, (cond_p or 0) if dWc else 0, B, H,
+                                C if dWc else 0))
+
+    def _run_tail(self, st):
+        jobs, self._tail_jobs = self._tail_jobs, []
+        if not jobs:
+            return
+        cache = self.__dict__.setdefault("_tail_cache", {})
+        key = tuple(jobs)
+        arrs = cache.get(key)
+        if arrs is None:
+            if len(cache) > 64:
+                cache.clear()
+            mx = self.lib.sca_grad_tail_max_jobs()
+            arrs = []
+            for lo in range(0, len(jobs), mx):
+                chunk = jobs[lo:lo + mx]
+                arr = (_lib.TailJob * len(chunk))()
+                for j, (kind, S, stride, src, dst, n, dWc, cond, B, H, C) in zip(arr, chunk):
+                    j.kind, j.S, j.stride, j.src, j.dst, j.n = kind, S, stride, src, dst or None, n
+                    j.dWc, j.cond, j.B, j.H, j.C = dWc or None, cond or None, B, H, C
+                arrs.append(arr)
+            cache[key] = arrs
+        for arr in arrs:
+            _lib.check(self.lib.sca_grad_tail(arr, len(arr), st), "grad_tail")
+
     def _layer_block_fwd(self, ly, sp, S, stride, B, cond_args, p_drop, mask_ptr, train, step_p, st):
         """Everything between two GEMMs of one layer: slab sum + bias + condition term, then LayerNorm or BatchNorm,
         ReLU, dropout.  Leaves the normalised pre-activation in ws[tag.yn] and the output in ws[tag.h]."""
@@ -426,7 +543,7 @@ class CVAEEngine:
                                 p_drop, mask_ptr, self.seed, ly.rng_stream, step_p, ws["bn_acc"].data_ptr(),
                                 ws[ly.tag + ".bnstats"].data_ptr(), h, st), "bn_fwd")
         if update:
-            self.buffers[ly.bn + ".num_batches_tracked"] += 1
+            self._call(self.buffers[ly.bn + ".num_batches_tracked"].add_, 1)
         return h
 
     # ------------------------------------------------------------------------------------------ the step
@@ -448,7 +565,6 @@ class CVAEEngine:
         cond_p = ptr(cond) if C > 0 else None
         step_p = self.step_ctr.data_ptr()
         masks = masks or {}
-        self._mmd_ns_cur = 0
         self._p_drop_cur, self._masks_cur = p_drop, masks
 
         # 1. minibatch gather (+ log1p, size factors)
@@ -461,6 +577,9 @@ class CVAEEngine:
             _lib.check(L.sca_csr_gather_rows(ip.data_ptr(), ix.data_ptr(), dv.data_ptr(), ptr(row_ids), B, G, log1p,
                                              ws["x"].data_ptr(), G, ws["sf"].data_ptr(), st), "csr_gather")
 
+        self._aux_q = []
+        self._tail_jobs = []
+        self._prologue(B, compute_grad)
         self._covs_cur = covs
         if self.cond_embed:
             self._embed_lookup(covs, B, st)
@@ -479,31 +598,39 @@ class CVAEEngine:
         a = ws["x"].data_ptr()
         for ly in self.enc:
             a = layer_forward(ly, a)
+        self._ev_pro = self._flush()
         # 3. heads + sampling + KL
         Hl = self.H[-1]
         sp, S, stride = self._gemm(0, 0, a, Hl, self.heads_w.data_ptr(), Hl, B, 2 * Z, Hl, st)
         _lib.check(L.sca_latent_fwd(sp, S, stride, self.heads_b.data_ptr(), B, Z, ptr(eps), self.seed, 1, step_p, 1,
                                     ws["mu_lv"].data_ptr(), ws["eps"].data_ptr(), ws["z"].data_ptr(),
                                     ws["kl_row"].data_ptr(), st), "latent_fwd")
-        # MMD (value + gradient w.r.t. z or y1) runs on the aux stream beside the decoder / reconstruction kernels
-        n_part = 0
+        # Side work is deferred: its dependency point is taken here, its launches are issued after the host has fed
+        # the main-stream chain (the step is launch-rate sensitive; the critical path must never wait for the host).
+        do_mmd = self.use_mmd and C > 0
+        self._n_part = 0
+        self._dz2_cur = (None, 0)
+        self._mmd_ev = None
 
-        def launch_mmd():
+        def mmd_work(sa):
             feat, Dm = (ws["z"], Z) if self.mmd_on == "z" else (ws["dec0.h"], self.dec[0].n_out)
-            sa = self._fork()
             _lib.check(L.sca_mmd_fwd_bwd(feat.data_ptr(), Dm, cond_p, B, Dm, C,
                                          -1 if self.boundary is None else int(self.boundary), self.beta,
                                          ws["Wt"].data_ptr(), ws["counts"].data_ptr(), ws["mmd_part"].data_ptr(),
                                          ws["mmd_g"].data_ptr() if compute_grad else None, B * Dm, sa), "mmd")
-            self._mmd_ns_cur = L.sca_mmd_num_slabs(B, Dm)
-            return L.sca_mmd_num_partials(B, Dm)
+            if compute_grad:      # the gradient slabs are summed here, off the critical path
+                _lib.check(L.sca_splitk_reduce(ws["mmd_g"].data_ptr(), L.sca_mmd_num_slabs(B, Dm), B * Dm,
+                                               ws["mmd_g1"].data_ptr(), B * Dm, sa), "mmd_reduce")
 
-        do_mmd = self.use_mmd and C > 0
+        def want_mmd():
+            Dm = Z if self.mmd_on == "z" else self.dec[0].n_out
+            self._n_part = L.sca_mmd_num_partials(B, Dm)
+            self._defer(mmd_work)
+
         if do_mmd and self.mmd_on == "z":
-            n_part = launch_mmd()
-        self._dz2_cur = (None, 0)
+            want_mmd()
         if self.cond_embed and proto is not None:
-            n_part = self._launch_proto(proto, B, compute_grad)
+            self._n_part = self._launch_proto(proto, B, compute_grad)
         if self.arch == "expimap":
             return self._expimap_tail(row_ids, cond_p, B, compute_grad, accumulate_logs, st)
         # 4. decoder
@@ -511,83 +638,107 @@ class CVAEEngine:
         for i, ly in enumerate(self.dec):
             a = layer_forward(ly, a)
             if i == 0 and do_mmd and self.mmd_on != "z":
-                n_part = launch_mmd()
+                want_mmd()
         Hd = self.dec[-1].n_out
-        # 5. output layer + reconstruction loss (+ gradient w.r.t. the logits, in place)
+        # 5. output layer(s); the aux stream meanwhile prepares the theta tables / zeroes the accumulating gradient
+        #    targets and runs the MMD / prototype losses
         self._gemm(0, 0, a, Hd, P[self.out_w].data_ptr(), Hd, B, G, Hd, st, out=ws["logits"].data_ptr(), ldc=G,
                    bias=P[self.out_b].data_ptr(), force_s1=True)
-        if compute_grad and self.trainable[self.out_b]:
-            self.g[self.out_b].zero_()          # accumulated by atomics; every other gradient is overwritten
+        zinb = self.recon == "zinb"
+        if zinb:
+            self._gemm(0, 0, a, Hd, P["decoder.dropout_decoder.weight"].data_ptr(), Hd, B, G, Hd, st,
+                       out=ws["pi"].data_ptr(), ldc=G, bias=P["decoder.dropout_decoder.bias"].data_ptr(),
+                       force_s1=True)
+        ev_side = self._flush()
+        self._wait(self._ev_pro)
+        # 6. reconstruction loss (+ gradient w.r.t. the logits, in place)
         rpb = max(1, B // 1024)
+        gob = self.g[self.out_b].data_ptr() if self.trainable[self.out_b] else None
         if self.recon == "mse":
             _lib.check(L.sca_mse_rows(ws["logits"].data_ptr(), G, ws["x"].data_ptr(), G, B, G, rpb,
-                                      ws["row_ll"].data_ptr(),
-                                      self.g[self.out_b].data_ptr() if self.trainable[self.out_b] else None,
-                                      int(compute_grad), 1, None, None, st),
-                       "mse_rows")
+                                      ws["row_ll"].data_ptr(), gob, int(compute_grad), 1, None, None, st), "mse_rows")
             recon_sign = 1.0
         else:
-            zinb = self.recon == "zinb"
-            if zinb:
-                self._gemm(0, 0, a, Hd, P["decoder.dropout_decoder.weight"].data_ptr(), Hd, B, G, Hd, st,
-                           out=ws["pi"].data_ptr(), ldc=G, bias=P["decoder.dropout_decoder.bias"].data_ptr(),
-                           force_s1=True)
-            _lib.check(L.sca_theta_prep(P["theta"].data_ptr(), G, max(C, 1), ws["tab_theta"].data_ptr(),
-                                        ws["tab_lte"].data_ptr(), st), "theta_prep")
-            if compute_grad:
-                ws["dthetaT"].zero_()
             ip, ix, dv = self.csr
             _lib.check(L.sca_recon_rows(int(zinb), ws["logits"].data_ptr(), G, ws["pi"].data_ptr() if zinb else None,
                                         ip.data_ptr(), ix.data_ptr(), dv.data_ptr(), ptr(row_ids),
                                         ws["sf"].data_ptr(), cond_p, ws["tab_theta"].data_ptr(),
                                         ws["tab_lte"].data_ptr(), B, G, max(C, 1), rpb, ws["row_ll"].data_ptr(),
-                                        ws["dthetaT"].data_ptr(),
-                                        self.g[self.out_b].data_ptr() if self.trainable[self.out_b] else None,
+                                        ws["dthetaT"].data_ptr(), gob,
                                         self.g["decoder.dropout_decoder.bias"].data_ptr()
                                         if zinb and self.trainable["decoder.dropout_decoder.bias"] else None,
                                         int(compute_grad), None, st), "recon_rows")
             recon_sign = -1.0
-        if n_part:
-            self._join()          # MMD / prototype-loss value (and gradient) are ready
-        _lib.check(L.sca_finalize_losses(ws["row_ll"].data_ptr(), recon_sign, ws["kl_row"].data_ptr(), B,
-                                         ws["mmd_part"].data_ptr(), n_part, self.hyper.data_ptr(),
-                                         self.losses.data_ptr(), self.accum.data_ptr() if accumulate_logs else None,
-                                         st), "finalize_losses")
+        self._defer_finalize(recon_sign, B, accumulate_logs)
         if not compute_grad:
+            self._wait(self._flush())
             return self.losses
-        self._backward(B, cond_p, p_drop, masks, st, n_part > 0 and do_mmd)
+        self._backward(B, cond_p, p_drop, masks, st, do_mmd, ev_side)
         return self.losses
 
-    def _backward(self, B, cond_p, p_drop, masks, st, have_mmd):
+    def _prologue(self, B, compute_grad):
+        """Start-of-step side work (aux stream, deferred): exp(theta) tables for the likelihood kernel and zeroing of
+        the gradient targets that kernels accumulate into with atomics (every other gradient is overwritten)."""
+        L, P, ws = self.lib, self.p, self.ws
+        G, C = self.G, max(self.C, 1)
+        xp_c = self.arch == "expimap" and self.xp_wc
+
+        def work(sa):
+            if self.recon != "mse":
+                _lib.check(L.sca_theta_prep(P["theta"].data_ptr(), G, C, ws["tab_theta"].data_ptr(),
+                                            ws["tab_lte"].data_ptr(), sa), "theta_prep")
+                if compute_grad:
+                    self._zero(ws["dthetaT"], sa)
+            if compute_grad:
+                # optimizer.zero_grad(): most gradients are overwritten, the accumulating ones (output bias, column
+                # sums of large batches, embedding scatter) need zeros - one memset of the flat buffer covers all
+                self._zero(self.flat_g, sa)
+            if xp_c:
+                _lib.check(L.sca_transpose_scale(P[self.xp_wc].data_ptr(), self.G, self.C, 1.0,
+                                                 ws["coffT"].data_ptr(), sa), "cond_transpose")
+        self._defer(work)
+
+    def _defer_finalize(self, recon_sign, B, accumulate_logs):
+        """Loss composition / epoch-log accumulation (aux stream: nothing on the critical path reads it)."""
+        L, ws = self.lib, self.ws
+        n_part = self._n_part
+
+        def work(sa):
+            _lib.check(L.sca_finalize_losses(ws["row_ll"].data_ptr(), recon_sign, ws["kl_row"].data_ptr(), B,
+                                             ws["mmd_part"].data_ptr(), n_part, self.hyper.data_ptr(),
+                                             self.losses.data_ptr(),
+                                             self.accum.data_ptr() if accumulate_logs else None, sa), "finalize")
+        self._defer(work)
+
+    def _backward(self, B, cond_p, p_drop, masks, st, have_mmd, ev_side):
         """Backward pass.  The dX chain (layer_bwd -> dX GEMM -> ...) is the critical path and stays on the main
-        stream; every weight / bias / condition-weight gradient only feeds Adam, so it is issued on the aux stream
+        stream; every weight / bias / condition-weight gradient only feeds Adam, so it is deferred to the aux stream
         (own slab workspace, per-layer `da` buffers) and joined once at the end."""
         L, P, Gd, ws, T = self.lib, self.p, self.g, self.ws, self.trainable
         G, C, Z = self.G, self.C, self.Zt
-        ptr = _lib.ptr
-        step_p = self.step_ctr.data_ptr()
         AUX = "slab_aux" if self.overlap else "slab"
         Hd = self.dec[-1].n_out
         h_last = ws[self.dec[-1].tag + ".h"].data_ptr()
         dl = ws["logits"].data_ptr()
 
         # ---- side work that depends only on the reconstruction kernel's outputs
-        sa = self._fork()
-        if self.recon != "mse" and T["theta"]:
-            # theta gradient: -1/B * sum_b theta dll/dtheta, transposed back to the [G][C] parameter layout
-            _lib.check(L.sca_transpose_scale(ws["dthetaT"].data_ptr(), max(C, 1), G, -1.0 / B,
-                                             Gd["theta"].data_ptr(), sa), "transpose_scale")
-        if T[self.out_w]:
-            self._gemm_to(1, 1, dl, G, h_last, Hd, G, Hd, B, sa, Gd[self.out_w], slab_key=AUX)
+        def recon_side(sa):
+            if self.recon != "mse" and T["theta"]:
+                # theta gradient: -1/B * sum_b theta dll/dtheta, transposed back to the [G][C] parameter layout
+                _lib.check(L.sca_transpose_scale(ws["dthetaT"].data_ptr(), max(C, 1), G, -1.0 / B,
+                                                 Gd["theta"].data_ptr(), sa), "transpose_scale")
+            if T[self.out_w]:
+                self._grad_gemm(1, 1, dl, G, h_last, Hd, G, Hd, B, sa, Gd[self.out_w])
+            if self.recon == "zinb" and T["decoder.dropout_decoder.weight"]:
+                self._grad_gemm(1, 1, ws["pi"].data_ptr(), G, h_last, Hd, G, Hd, B, sa,
+                                Gd["decoder.dropout_decoder.weight"])
+        self._defer(recon_side)
         extra = None
         if self.recon == "zinb":
-            dp = ws["pi"].data_ptr()
-            if T["decoder.dropout_decoder.weight"]:
-                self._gemm_to(1, 1, dp, G, h_last, Hd, G, Hd, B, sa, Gd["decoder.dropout_decoder.weight"],
-                              slab_key=AUX)
             # dh = dl @ Wo + dpi @ Wp : the second product is reduced into a scratch [B, Hd] and joins as `extra`
             scratch = self._scratch_bh(B, Hd)
-            self._gemm_to(0, 1, dp, G, P["decoder.dropout_decoder.weight"].data_ptr(), Hd, B, Hd, G, st, scratch)
+            self._gemm_to(0, 1, ws["pi"].data_ptr(), G, P["decoder.dropout_decoder.weight"].data_ptr(), Hd, B, Hd, G,
+                          st, scratch)
             extra = scratch.data_ptr()
         sp, S, stride = self._gemm(0, 1, dl, G, P[self.out_w].data_ptr(), Hd, B, Hd, G, st)
 
@@ -596,22 +747,27 @@ class CVAEEngine:
             ly = self.dec[li]
             if li == 0 and have_mmd and self.mmd_on == "y":
                 # gradient of the MMD on y1 joins the upstream gradient of the first decoder layer
-                _lib.check(L.sca_splitk_reduce(ws["mmd_g"].data_ptr(), self._mmd_ns_cur, B * ly.n_out,
-                                               ws["mmd_extra"].data_ptr(), B * ly.n_out, st), "mmd_reduce")
+                self._wait(ev_side)
                 if extra is not None:       # single-hidden-layer ZINB net: both extras land on the same layer
-                    ws["mmd_extra"].view(-1)[:B * ly.n_out].add_(self._scratch_bh(B, ly.n_out).view(-1))
-                extra = ws["mmd_extra"].data_ptr()
+                    n = B * ly.n_out
+                    self._call(ws["mmd_g1"].view(-1)[:n].add_, self._scratch_bh(B, ly.n_out).view(-1))
+                extra = ws["mmd_g1"].data_ptr()
             a_prev = ws["z"].data_ptr() if li == 0 else ws[self.dec[li - 1].tag + ".h"].data_ptr()
             sp, S, stride = self._layer_backward(ly, a_prev, sp, S, stride, extra, True, B, cond_p, p_drop, masks, st)
             extra = None
 
-        use_mz = have_mmd and self.mmd_on == "z"
-        dz2, S2 = (ws["mmd_g"].data_ptr(), self._mmd_ns_cur) if use_mz else self._dz2_cur
+        if have_mmd and self.mmd_on == "z":
+            dz2, S2 = ws["mmd_g1"].data_ptr(), 1
+        else:
+            dz2, S2 = self._dz2_cur
+        if S2:
+            self._wait(ev_side)         # MMD / prototype gradient w.r.t. z (finished long ago on the aux stream)
         self._backward_latent_encoder(B, cond_p, p_drop, masks, st, sp, S, stride, dz2, S2)
 
     def _layer_backward(self, ly, a_prev, sp, S, stride, extra, need_dx, B, cond_p, p_drop, masks, st):
-        """Gradient through one Linear(+cond) -> norm -> ReLU -> dropout block: `da` on the main stream, the weight /
-        bias / condition-weight gradients on the aux stream, then (need_dx) the dX GEMM slabs for the layer below."""
+        """Gradient through one Linear(+cond) -> norm -> ReLU -> dropout block: `da` and (need_dx) the dX GEMM slabs for
+        the layer below on the main stream; the weight / bias / condition-weight gradients are deferred to the aux
+        stream."""
         L, P, Gd, ws, T = self.lib, self.p, self.g, self.ws, self.trainable
         C = self.C
         ptr = _lib.ptr
@@ -632,34 +788,33 @@ class CVAEEngine:
         need_w = T[ly.w]
         need_b = bool(ly.b) and T[ly.b]
         need_c = bool(ly.wc) and T[ly.wc]
-        if need_w or need_b or need_c:
-            sa = self._fork()
+        need_e = self.cond_embed and bool(ly.wc) and any(T[k] for (k, _, _) in self.emb)
+
+        def side(sa):
             if need_w:
-                self._gemm_to(1, 1, da, ly.n_out, a_prev, ly.n_in, ly.n_out, ly.n_in, B, sa, Gd[ly.w],
-                              slab_key=AUX)
+                self._grad_gemm(1, 1, da, ly.n_out, a_prev, ly.n_in, ly.n_out, ly.n_in, B, sa, Gd[ly.w])
             if self.cond_embed:
                 if need_c:       # dWc [H, E] = da^T @ cvec
-                    self._gemm_to(1, 1, da, ly.n_out, ws["cvec"].data_ptr(), self.E, ly.n_out, self.E, B, sa,
-                                  Gd[ly.wc], slab_key=AUX)
+                    self._grad_gemm(1, 1, da, ly.n_out, ws["cvec"].data_ptr(), self.E, ly.n_out, self.E, B, sa,
+                                    Gd[ly.wc])
                 if need_b:
-                    _lib.check(L.sca_cond_colsum(da, B, ly.n_out, None, 0, ws["segT"].data_ptr(), None,
-                                                 Gd[ly.b].data_ptr(), sa), "bias_colsum")
+                    self._colsum(da, B, ly.n_out, None, 0, None, Gd[ly.b].data_ptr(), sa)
+                if need_e:
+                    # gradient w.r.t. the dense condition vector: dcvec [B, E] = da @ Wc (scattered into the
+                    # embedding tables at the end of the backward pass)
+                    self._gemm_to(0, 1, da, ly.n_out, P[ly.wc].data_ptr(), self.E, B, self.E, ly.n_out, sa,
+                                  ws["dcvec_enc" if ly.tag.startswith("enc") else "dcvec_dec"], slab_key=AUX)
             elif need_b or need_c:
-                _lib.check(L.sca_cond_colsum(da, B, ly.n_out, cond_p if ly.wc else None, C if ly.wc else 0,
-                                             ws["segT"].data_ptr(), Gd[ly.wc].data_ptr() if need_c else None,
-                                             Gd[ly.b].data_ptr() if need_b else None, sa), "cond_colsum")
-        if self.cond_embed and ly.wc and any(T[k] for (k, _, _) in self.emb):
-            # gradient w.r.t. the dense condition vector: dcvec [B, E] = da @ Wc  (scattered into the embedding
-            # tables at the end of the backward pass)
-            sa = self._fork()
-            self._gemm_to(0, 1, da, ly.n_out, P[ly.wc].data_ptr(), self.E, B, self.E, ly.n_out, sa,
-                          ws["dcvec_enc" if ly.tag.startswith("enc") else "dcvec_dec"], slab_key=AUX)
+                self._colsum(da, B, ly.n_out, cond_p, C, Gd[ly.wc].data_ptr() if need_c else None,
+                             Gd[ly.b].data_ptr() if need_b else None, sa)
+        if need_w or need_b or need_c or need_e:
+            self._defer(side)
         if need_dx:
             return self._gemm(0, 1, da, ly.n_out, P[ly.w].data_ptr(), ly.n_in, B, ly.n_in, ly.n_out, st)
         return None, 0, 0
 
     def _backward_latent_encoder(self, B, cond_p, p_drop, masks, st, sp, S, stride, dz2, S2):
-        """Latent block (dz from the decoder + dz2 from MMD / HSIC + KL) -> heads -> encoder layers, last -> first."""
+        """Latent block (dz from the decoder + dz2 from MMD / HSIC / prototypes + KL) -> heads -> encoder layers."""
         L, ws, T = self.lib, self.ws, self.trainable
         Z = self.Zt
         AUX = "slab_aux" if self.overlap else "slab"
@@ -669,14 +824,13 @@ class CVAEEngine:
         Hl = self.H[-1]
         h_enc = ws[self.enc[-1].tag + ".h"].data_ptr()
         dh = ws["dheads"].data_ptr()
-        heads_t = [T[k] for k in self.heads_names]
-        if any(heads_t):
+        if any(T[k] for k in self.heads_names):
             # mean / log_var (/ expand) heads share one fused gradient GEMM; a frozen member's slice of the result is
             # simply never consumed by Adam (trainable_ranges() skips it)
-            sa = self._fork()
-            self._gemm_to(1, 1, dh, 2 * Z, h_enc, Hl, 2 * Z, Hl, B, sa, self.heads_gw, slab_key=AUX)
-            _lib.check(L.sca_cond_colsum(dh, B, 2 * Z, None, 0, ws["segT"].data_ptr(), None,
-                                         self.heads_gb.data_ptr(), sa), "heads_bias")
+            def heads_side(sa):
+                self._grad_gemm(1, 1, dh, 2 * Z, h_enc, Hl, 2 * Z, Hl, B, sa, self.heads_gw)
+                self._colsum(dh, B, 2 * Z, None, 0, None, self.heads_gb.data_ptr(), sa)
+            self._defer(heads_side)
         sp, S, stride = self._gemm(0, 1, dh, 2 * Z, self.heads_w.data_ptr(), Hl, B, Hl, 2 * Z, st)
         for li in range(len(self.enc) - 1, -1, -1):
             ly = self.enc[li]
@@ -684,8 +838,9 @@ class CVAEEngine:
             sp, S, stride = self._layer_backward(ly, a_prev, sp, S, stride, None, li > 0, B, cond_p, p_drop, masks,
                                                  st)
         if self.cond_embed and any(T[k] for (k, _, _) in self.emb):
-            self._embed_scatter(B)
-        self._join()
+            self._defer(lambda sa: self._embed_scatter(B, sa))
+        self._defer(self._run_tail)
+        self._wait(self._flush())
 
     # ------------------------------------------------------------------------------------------ scPoli
     def _embed_lookup(self, covs, B, st):
@@ -701,23 +856,21 @@ class CVAEEngine:
                                           self.E, st), "embed_lookup")
             col += e
 
-    def _embed_scatter(self, B):
+    def _embed_scatter(self, B, sa):
         """Embedding gradients: scatter-add of dcvec (encoder + decoder injection sites) on the aux stream."""
         L, ws, Gd, T = self.lib, self.ws, self.g, self.trainable
-        sa = self._fork()
         covs = self._covs_cur
         ga = ws["dcvec_enc"].data_ptr() if self.enc[0].wc else None
         gb = ws["dcvec_dec"].data_ptr() if self.dec[0].wc else None
         col = 0
-        with torch.cuda.stream(self.aux if self.overlap else torch.cuda.current_stream(self.device)):
-            for i, (k, n, e) in enumerate(self.emb):
-                if T[k]:
-                    Gd[k].zero_()
-                    _lib.check(L.sca_embed_scatter_add(None if ga is None else ga + 4 * col,
-                                                       None if gb is None else gb + 4 * col, self.E, B, e, n,
-                                                       covs.data_ptr() + 4 * i, len(self.emb), Gd[k].data_ptr(), sa),
-                               "embed_scatter")
-                col += e
+        for i, (k, n, e) in enumerate(self.emb):
+            if T[k]:
+                self._zero(Gd[k], sa)
+                _lib.check(L.sca_embed_scatter_add(None if ga is None else ga + 4 * col,
+                                                   None if gb is None else gb + 4 * col, self.E, B, e, n,
+                                                   covs.data_ptr() + 4 * i, len(self.emb), Gd[k].data_ptr(), sa),
+                           "embed_scatter")
+            col += e
 
     def _launch_proto(self, proto, B, compute_grad):
         """eta * (labeled + unlabeled_weight * unlabeled) prototype loss on z (trainers/scpoli/trainer.py:542-575) on the
@@ -733,12 +886,15 @@ class CVAEEngine:
             ws["proto_work"] = torch.empty(need, dtype=torch.uint8, device=self.device)
         ct, lab = proto.get("celltypes"), proto.get("labeled")
         eta, uw = float(proto.get("eta", 1.0)), float(proto.get("unlabeled_weight", 0.0))
-        sa = self._fork()
-        _lib.check(L.sca_proto_loss(ws["z"].data_ptr(), self.Zt, B, self.Zt, _lib.ptr(Pl), K, _lib.ptr(ct),
-                                    0 if ct is None else ct.shape[1], _lib.ptr(lab), eta, _lib.ptr(Pu), Ku, eta * uw,
-                                    ws["proto_work"].data_ptr(), ws["mmd_part"].data_ptr(),
-                                    ws["proto_raw"].data_ptr(), 1,
-                                    ws["proto_dz"].data_ptr() if compute_grad else None, self.Zt, None, sa), "proto")
+
+        def work(sa):
+            _lib.check(L.sca_proto_loss(ws["z"].data_ptr(), self.Zt, B, self.Zt, _lib.ptr(Pl), K, _lib.ptr(ct),
+                                        0 if ct is None else ct.shape[1], _lib.ptr(lab), eta, _lib.ptr(Pu), Ku,
+                                        eta * uw, ws["proto_work"].data_ptr(), ws["mmd_part"].data_ptr(),
+                                        ws["proto_raw"].data_ptr(), 1,
+                                        ws["proto_dz"].data_ptr() if compute_grad else None, self.Zt, None, sa),
+                       "proto")
+        self._defer(work)
         if compute_grad:
             self._dz2_cur = (ws["proto_dz"].data_ptr(), 1)
         return 1
@@ -746,16 +902,13 @@ class CVAEEngine:
     # ------------------------------------------------------------------------------------------ expiMap
     def _expimap_pack(self, st):
         """Weff [G][Zt] = [expr_L.weight*mask | ext_L_m.weight*ext_mask | ext_L.weight] (column order of
-        MaskedCondLayers.forward) and the transposed condition weights."""
+        MaskedCondLayers.forward)."""
         L, P, ws = self.lib, self.p, self.ws
         Zt, col = self.Zt, 0
         for (k, w, _), md in zip(self.xp_parts, self.xp_masks):
             _lib.check(L.sca_masked_copy(P[k].data_ptr(), w, _lib.ptr(md), w, ws["Weff"].data_ptr() + 4 * col, Zt,
                                          self.G, w, st), "masked_copy")
             col += w
-        if self.xp_wc:
-            _lib.check(L.sca_transpose_scale(P[self.xp_wc].data_ptr(), self.G, self.C, 1.0,
-                                             ws["coffT"].data_ptr(), st), "cond_transpose")
 
     def _expimap_tail(self, row_ids, cond_p, B, compute_grad, accumulate_logs, st):
         """Decoder + losses + backward of expiMap after the latent block (models/expimap/expimap.py:180-222)."""
@@ -764,23 +917,24 @@ class CVAEEngine:
         ptr = _lib.ptr
         AUX = "slab_aux" if self.overlap else "slab"
         # HSIC between annotated and unconstrained latent columns, beside the decoder (aux stream)
-        n_part = 0
         if self.use_hsic:
-            sa = self._fork()
-            if compute_grad:
-                with torch.cuda.stream(self.aux if self.overlap else torch.cuda.current_stream(self.device)):
-                    ws["hsic_dz"].zero_()
-            side = ws["hsic_side"]
-            for i, (sig_a, sig_b) in enumerate(self._hsic_sigmas):
-                _lib.check(L.sca_hsic_fwd_bwd(ws["z"].data_ptr(), Zt, B, Zt, side[i].data_ptr(), sig_a, sig_b,
-                                              self.hsic_beta, ws["hsic_work"].data_ptr(), ws["mmd_part"].data_ptr(),
-                                              ws["hsic_raw"].data_ptr(), int(i > 0),
-                                              ws["hsic_dz"].data_ptr() if compute_grad else None, Zt, sa), "hsic")
-            n_part = 1
+            def hsic_work(sa):
+                if compute_grad:
+                    self._zero(ws["hsic_dz"], sa)
+                side = ws["hsic_side"]
+                for i, (sig_a, sig_b) in enumerate(self._hsic_sigmas):
+                    _lib.check(L.sca_hsic_fwd_bwd(ws["z"].data_ptr(), Zt, B, Zt, side[i].data_ptr(), sig_a, sig_b,
+                                                  self.hsic_beta, ws["hsic_work"].data_ptr(),
+                                                  ws["mmd_part"].data_ptr(), ws["hsic_raw"].data_ptr(), int(i > 0),
+                                                  ws["hsic_dz"].data_ptr() if compute_grad else None, Zt, sa), "hsic")
+            self._defer(hsic_work)
+            self._n_part = 1
         self._expimap_pack(st)
         coff = ws["coffT"].data_ptr() if self.xp_wc else None
         self._gemm(0, 0, ws["z"].data_ptr(), Zt, ws["Weff"].data_ptr(), Zt, B, G, Zt, st,
                    out=ws["logits"].data_ptr(), ldc=G, force_s1=True)
+        ev_side = self._flush()
+        self._wait(self._ev_pro)
         rpb = max(1, B // 1024)
         if self.recon == "mse":
             _lib.check(L.sca_mse_rows(ws["logits"].data_ptr(), G, ws["x"].data_ptr(), G, B, G, rpb,
@@ -788,10 +942,6 @@ class CVAEEngine:
                        "mse_rows")
             recon_sign = 1.0
         else:
-            _lib.check(L.sca_theta_prep(P["theta"].data_ptr(), G, max(C, 1), ws["tab_theta"].data_ptr(),
-                                        ws["tab_lte"].data_ptr(), st), "theta_prep")
-            if compute_grad:
-                ws["dthetaT"].zero_()
             ip, ix, dv = self.csr
             _lib.check(L.sca_recon_rows(0, ws["logits"].data_ptr(), G, None, ip.data_ptr(), ix.data_ptr(),
                                         dv.data_ptr(), ptr(row_ids), ws["sf"].data_ptr(), cond_p,
@@ -799,34 +949,32 @@ class CVAEEngine:
                                         ws["row_ll"].data_ptr(), ws["dthetaT"].data_ptr(), None, None,
                                         int(compute_grad), coff, st), "recon_rows")
             recon_sign = -1.0
-        if n_part:
-            self._join()
-        _lib.check(L.sca_finalize_losses(ws["row_ll"].data_ptr(), recon_sign, ws["kl_row"].data_ptr(), B,
-                                         ws["mmd_part"].data_ptr(), n_part, self.hyper.data_ptr(),
-                                         self.losses.data_ptr(), self.accum.data_ptr() if accumulate_logs else None,
-                                         st), "finalize_losses")
+        self._defer_finalize(recon_sign, B, accumulate_logs)
         if not compute_grad:
+            self._wait(self._flush())
             return self.losses
         # ---- backward: weight-side gradients on the aux stream, dz on the main stream
         dl = ws["logits"].data_ptr()
-        sa = self._fork()
-        if self.recon != "mse" and T["theta"]:
-            _lib.check(L.sca_transpose_scale(ws["dthetaT"].data_ptr(), max(C, 1), G, -1.0 / B,
-                                             Gd["theta"].data_ptr(), sa), "transpose_scale")
-        if any(T[k] for (k, _, _) in self.xp_parts):
-            self._gemm_to(1, 1, dl, G, ws["z"].data_ptr(), Zt, G, Zt, B, sa, ws["dWeff"], slab_key=AUX)
-            col = 0
-            for (k, w, _), md in zip(self.xp_parts, self.xp_masks):
-                if T[k]:
-                    _lib.check(L.sca_masked_copy(ws["dWeff"].data_ptr() + 4 * col, Zt, ptr(md), w,
-                                                 Gd[k].data_ptr(), w, G, w, sa), "masked_unpack")
-                col += w
-        if self.xp_wc and T[self.xp_wc]:
-            _lib.check(L.sca_cond_colsum(dl, B, G, cond_p, C, ws["segT"].data_ptr(), Gd[self.xp_wc].data_ptr(),
-                                         None, sa), "cond_colsum")
+
+        def side(sa):
+            if self.recon != "mse" and T["theta"]:
+                _lib.check(L.sca_transpose_scale(ws["dthetaT"].data_ptr(), max(C, 1), G, -1.0 / B,
+                                                 Gd["theta"].data_ptr(), sa), "transpose_scale")
+            if any(T[k] for (k, _, _) in self.xp_parts):
+                self._gemm_to(1, 1, dl, G, ws["z"].data_ptr(), Zt, G, Zt, B, sa, ws["dWeff"], slab_key=AUX)
+                col = 0
+                for (k, w, _), md in zip(self.xp_parts, self.xp_masks):
+                    if T[k]:
+                        _lib.check(L.sca_masked_copy(ws["dWeff"].data_ptr() + 4 * col, Zt, ptr(md), w,
+                                                     Gd[k].data_ptr(), w, G, w, sa), "masked_unpack")
+                    col += w
+            if self.xp_wc and T[self.xp_wc]:
+                self._colsum(dl, B, G, cond_p, C, Gd[self.xp_wc].data_ptr(), None, sa)
+        self._defer(side)
         sp, S, stride = self._gemm(0, 1, dl, G, ws["Weff"].data_ptr(), Zt, B, Zt, G, st)
-        p_drop = self._p_drop_cur
-        self._backward_latent_encoder(B, cond_p, p_drop, self._masks_cur, st, sp, S, stride,
+        if self.use_hsic:
+            self._wait(ev_side)
+        self._backward_latent_encoder(B, cond_p, self._p_drop_cur, self._masks_cur, st, sp, S, stride,
                                       ws["hsic_dz"].data_ptr() if self.use_hsic else None,
                                       1 if self.use_hsic else 0)
         return self.losses
@@ -867,76 +1015,125 @@ class CVAEEngine:
                                        self.flat_m[s:].data_ptr(), self.flat_v[s:].data_ptr(), e - s,
                                        self.hyper.data_ptr(), 0.9, 0.999, wd, st), "adam")
 
-    # ------------------------------------------------------------------------------------------ HIP-graph step
+    # ------------------------------------------------------------------------------------------ whole step
     def train_step(self, row_ids, cond, B, alpha_kl, lr, eps=0.01, clip=0.0, weight_decay=0.04, world=1,
-                   use_graph="auto"):
+                   use_graph="auto", wd_overrides=None, grad_weight=None):
         """One optimisation step: forward + backward (+ gradient all-reduce) + Adam.
 
-        With use_graph the launch sequence of this batch size is captured once into HIP graphs (all per-step
-        scalars live in device memory: `hyper`, `step_ctr`; minibatch ids are copied into static buffers) and
-        replayed: ~60 kernel launches cost one graph launch on the host.  "auto" replays graphs for B <= 2048
-        (launch-bound: 0.54 -> 0.39 ms at B=128) and launches eagerly above (GPU-bound; measured at B=4096 the
-        two-stream eager schedule is ~7% faster than the graph's dependency handling)."""
+        All per-step scalars live in device memory (`hyper`, `step_ctr`) and the minibatch ids are copied into static
+        buffers, so the launch sequence of a given batch size never changes.  It is recorded once and then either
+          * "plan" : re-issued from the recorded (function, arguments) list - no Python work per launch besides the
+                     ctypes call itself, launches stay in the hand-ordered main-first sequence;
+          * True   : replayed as HIP graphs (one graph launch per step; measured fastest at every batch size:
+                     0.25 / 0.32 / 0.50 / 2.03 ms at B = 128 / 1024 / 4096 / 16384 on MI355X) - the "auto" default;
+          * False  : launched eagerly through the normal Python path."""
         if use_graph == "auto":
-            use_graph = B <= 2048
+            use_graph = True
         self.begin_step(alpha_kl, lr, eps, clip)
-        if not use_graph:
+        if use_graph is False:
             self.forward_backward(row_ids, cond, B)
             if world > 1:
                 from . import distributed as sdist
-                sdist.allreduce_mean_(self.flat_g, world)
-            self.adam_step(weight_decay)
+                sdist.allreduce_mean_(self.flat_g, world, weight=grad_weight)
+            self.adam_step(weight_decay, wd_overrides)
             return self.losses
-        key = (B, float(weight_decay), world > 1, tuple(sorted(k for k, v in self.trainable.items() if v)),
-               self.use_mmd, self.mmd_on, self.boundary, self.beta)
-        g = self._graphs.get(key) if hasattr(self, "_graphs") else None
+        key = (B, use_graph is True, float(weight_decay), tuple(sorted((wd_overrides or {}).items())), world > 1,
+               tuple(sorted(k for k, v in self.trainable.items() if v)), self.use_mmd, self.mmd_on, self.boundary,
+               self.beta, torch.cuda.current_stream(self.device).cuda_stream)
+        plans = self.__dict__.setdefault("_plans", {})
+        g = plans.get(key)
         if g is None:
-            g = self._capture(B, weight_decay, world > 1, key)
+            g = plans[key] = (self._capture if use_graph is True else self._record)(B, weight_decay, wd_overrides,
+                                                                                    world > 1)
         g["rows"].copy_(row_ids, non_blocking=True)
         g["cond"].copy_(cond, non_blocking=True)
-        g["fwd"].replay()
+        if use_graph is True:
+            g["fwd"].replay()
+        else:
+            self._replay(g["fwd"])
         if world > 1:
             from . import distributed as sdist
-            sdist.allreduce_mean_(self.flat_g, world)
-            g["adam"].replay()
+            sdist.allreduce_mean_(self.flat_g, world, weight=grad_weight)
+            if use_graph is True:
+                g["adam"].replay()
+            else:
+                self._replay(g["adam"])
         return self.losses
 
-    def _capture(self, B, weight_decay, split, key):
-        if not hasattr(self, "_graphs"):
-            self._graphs = {}
+    @staticmethod
+    def _replay(plan):
+        for fn, args, checked in plan:
+            rc = fn(*args)
+            if checked and rc:
+                _lib.check(rc, "replayed launch")
+
+    def _warm(self, B, weight_decay, wd_overrides):
+        """Static minibatch buffers + one throw-away step (workspaces, lazy module loads) that leaves parameters,
+        Adam state and log accumulators untouched."""
         self._ensure(B)
         rows = torch.zeros(B, dtype=torch.int64, device=self.device)
         cond = torch.zeros(B, dtype=torch.int32, device=self.device)
-        # warm-up on a side stream (workspaces, lazy module loads), leaving parameters / Adam state untouched
-        snap = (self.flat_p.clone(), self.flat_m.clone(), self.flat_v.clone(), self.accum.clone())
+        snap = (self.flat_p.clone(), self.flat_m.clone(), self.flat_v.clone(), self.accum.clone(),
+                {k: v.clone() for k, v in self.buffers.items()})
+        self.forward_backward(rows, cond, B)
+        self.adam_step(weight_decay, wd_overrides)
+        torch.cuda.synchronize(self.device)
+        return rows, cond, snap
+
+    def _restore(self, snap):
+        torch.cuda.synchronize(self.device)
+        self.flat_p.copy_(snap[0]); self.flat_m.copy_(snap[1]); self.flat_v.copy_(snap[2]); self.accum.copy_(snap[3])
+        for k, v in snap[4].items():
+            self.buffers[k].copy_(v)
+
+    def _record(self, B, weight_decay, wd_overrides, split):
+        """Record the launch plan of one step (the launches are executed while being recorded)."""
+        rows, cond, snap = self._warm(B, weight_decay, wd_overrides)
+        out = dict(rows=rows, cond=cond)
+        self._rec = []
+        try:
+            self.forward_backward(rows, cond, B)
+            if split:
+                out["fwd"], self._rec = self._rec, []
+            self.adam_step(weight_decay, wd_overrides)
+            out["adam" if split else "fwd"] = self._rec
+        finally:
+            self._rec = None
+        self._restore(snap)
+        return out
+
+    def _capture(self, B, weight_decay, wd_overrides, split):
+        """Capture the step into HIP graphs."""
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
-            self.forward_backward(rows, cond, B)
-            self.adam_step(weight_decay)
+            rows, cond, snap = self._warm(B, weight_decay, wd_overrides)
         torch.cuda.current_stream(self.device).wait_stream(s)
-        torch.cuda.synchronize(self.device)
         out = dict(rows=rows, cond=cond)
         gf = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gf):
             self.forward_backward(rows, cond, B)
             if not split:
-                self.adam_step(weight_decay)
+                self.adam_step(weight_decay, wd_overrides)
         out["fwd"] = gf
         if split:
             ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga):
-                self.adam_step(weight_decay)
+                self.adam_step(weight_decay, wd_overrides)
             out["adam"] = ga
-        torch.cuda.synchronize(self.device)
-        self.flat_p.copy_(snap[0]); self.flat_m.copy_(snap[1]); self.flat_v.copy_(snap[2]); self.accum.copy_(snap[3])
-        self._graphs[key] = out
+        self._restore(snap)
         return out
 
     def begin_step(self, alpha_kl, lr, eps=0.01, clip=0.0):
+        """Per-step scalars -> device (`hyper`), Philox step counter += 1: one tiny kernel, no host staging."""
         self.adam_t += 1
-        self.set_hyper(alpha_kl=alpha_kl, lr=lr, eps=eps, clip=clip, t=self.adam_t)
-        self.step_ctr += 1
+        t = self.adam_t
+        h = self._hyper_host
+        h[0], h[1], h[2], h[3], h[4], h[5] = alpha_kl, lr, 1.0 - 0.9 ** t, math.sqrt(1.0 - 0.999 ** t), eps, clip
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self.lib._lib.sca_begin_step(self.hyper.data_ptr(), self.step_ctr.data_ptr(), float(alpha_kl),
+                                                float(lr), float(h[2]), float(h[3]), float(eps), float(clip), st),
+                   "begin_step")
 
     # ------------------------------------------------------------------------------------------ inference
     def encode(self, row_ids, cond, B, mean=True, x_dense=None, eps=None, covs=None):

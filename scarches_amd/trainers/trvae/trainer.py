@@ -61,6 +61,9 @@ class Trainer:
         self.seed = kwargs.pop("seed", 2020)
         self.monitor = kwargs.pop("monitor", True)
         self.monitor_only_val = kwargs.pop("monitor_only_val", True)
+        # how the engine issues a step: "auto" (HIP graph for small batches, recorded launch plan above), "plan",
+        # True (graph) or False (eager Python launches)
+        self.launch_mode = kwargs.pop("launch_mode", "auto")
         self.early_stopping = EarlyStopping(**early_stopping_kwargs)
 
         torch.manual_seed(self.seed)
@@ -189,17 +192,21 @@ class Trainer:
         raise NotImplementedError
 
     def on_iteration(self, batch_data):
+        """zero_grad / backward / clip / step of the reference (trainer.py:262-280) as ONE engine step: forward +
+        hand-written backward (+ gradient all-reduce) + Adam, replayed from a recorded launch plan / HIP graph."""
         eng = self.engine
-        eng.begin_step(alpha_kl=self.calc_alpha_coeff(), lr=self.optimizer.param_groups[0]["lr"], eps=self._eps,
-                       clip=self.clip_value)
-        if batch_data[0].numel() > 0:
-            self.current_loss = self.loss(batch_data)
-        else:                       # a rank whose slice of a tiny last minibatch is empty contributes zeros
+        rows, cond, n_global = batch_data
+        kw = dict(alpha_kl=self.calc_alpha_coeff(), lr=self.optimizer.param_groups[0]["lr"], eps=self._eps,
+                  clip=self.clip_value)
+        if rows.numel() == 0:           # a rank whose slice of a tiny last minibatch is empty contributes zeros
+            eng.begin_step(**kw)
             eng.flat_g.zero_()
-        if self.world > 1:
-            # exact global-minibatch gradient also when the shards are ragged (last partial minibatch)
-            sdist.allreduce_mean_(eng.flat_g, self.world, weight=batch_data[0].numel() / batch_data[2])
-        eng.adam_step(weight_decay=self.weight_decay)
+            sdist.allreduce_mean_(eng.flat_g, self.world, weight=0.0)
+            eng.adam_step(weight_decay=self.weight_decay)
+            return
+        self.current_loss = eng.train_step(rows, cond, rows.numel(), weight_decay=self.weight_decay,
+                                           world=self.world, use_graph=self.launch_mode,
+                                           grad_weight=rows.numel() / n_global if self.world > 1 else None, **kw)
 
     def _read_logs(self, prefix):
         acc = self.engine.accum.clone()
