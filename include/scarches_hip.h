@@ -128,7 +128,7 @@ int sca_finalize_losses(const float* row_recon, float recon_sign, const float* r
  * GEMM (as sca_splitk_reduce), kind 1 is the column reduction of sca_cond_colsum (db[h] = sum_b da[b][h], dWc[h][c] =
  * sum over rows with cond == c; autograd of the bias broadcast / one-hot GEMM of CondLayers, modules.py:21-27).
  * `jobs` is a HOST array (copied into the kernel arguments); at most sca_grad_tail_max_jobs() jobs, C <= 512.
- * For B > 1024 the kind-1 targets (db, dWc) are accumulated with atomics and must be zeroed by the caller. */
+ * For B > 256 the kind-1 targets (db, dWc) are accumulated with atomics and must be zeroed by the caller. */
 typedef struct {
     int32_t kind;          /* 0: dst[i] = sum_s src[s*stride + i], i < n;  1: column sums of da [B][H] */
     int32_t S;

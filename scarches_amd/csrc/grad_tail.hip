@@ -5,7 +5,7 @@
 //   db[h] = sum_b da[b][h],   dWc[h][c] = sum_{b: cond[b] = c} da[b][h]
 // (scarches/models/trvae/modules.py:21-27 CondLayers, nn.Linear biases).  As separate kernels these were ~20 tiny
 // launches per step, each paying the ~5 us launch floor; here they are jobs of one kernel.  Column-sum jobs split
-// the batch into 1024-row chunks; with more than one chunk the partial sums are added with float atomics, so the
+// the batch into 256-row chunks; with more than one chunk the partial sums are added with float atomics, so the
 // caller must have zeroed db / dWc (the engine zeroes the whole flat gradient buffer at the start of a step).  The job table travels by
 // value in the kernel arguments (no device-side table, nothing to upload).
 #include "common.h"
@@ -29,7 +29,7 @@ namespace {
 constexpr int TAIL_MAX_JOBS = 24;
 constexpr int TAIL_COLS = 16;          // columns per workgroup of a column-sum job (16 x 16 thread layout)
 constexpr int TAIL_MAX_C = 512;        // conditions whose segment table fits LDS: 512 * 16 * 4 B = 32 KB
-constexpr int TAIL_ROWS = 1024;        // batch rows per workgroup of a column-sum job (more chunks -> float atomics)
+constexpr int TAIL_ROWS = 256;         // batch rows per workgroup of a column-sum job (more chunks -> float atomics)
 
 struct TailArgs {
     sca_tail_job job[TAIL_MAX_JOBS];
@@ -48,8 +48,17 @@ __global__ __launch_bounds__(256) void grad_tail_kernel(const TailArgs a) {
         if (i0 >= J.n) return;
         if (i0 + 3 < J.n && (J.stride & 3) == 0 && (((uintptr_t)J.src | (uintptr_t)J.dst) & 15) == 0) {
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int s = 0; s < J.S; ++s) {
-                const float4 v = *reinterpret_cast<const float4*>(J.src + s * J.stride + i0);
+            const float* p = J.src + i0;
+            int s = 0;
+            for (; s + 8 <= J.S; s += 8) {          // 8 independent 16-byte loads in flight per thread
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(p + (s + u) * J.stride);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+            for (; s < J.S; ++s) {
+                const float4 v = *reinterpret_cast<const float4*>(p + s * J.stride);
                 acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
             }
             *reinterpret_cast<float4*>(J.dst + i0) = acc;
@@ -73,16 +82,28 @@ __global__ __launch_bounds__(256) void grad_tail_kernel(const TailArgs a) {
     __syncthreads();
     if (h < J.H) {
         // condition-sorted minibatches: a register accumulates the current run, one LDS atomic per run change
+        constexpr int RG = 256 / TAIL_COLS, U = 4;
         int cur = -1;
         float acc = 0.f;
-        for (int r = r_lo + ry; r < r_hi; r += 256 / TAIL_COLS) {
-            const int c = J.dWc ? J.cond[r] : 0;
-            if (c != cur) {
-                if (cur >= 0) atomicAdd(&seg[cur * TAIL_COLS + cx], acc);
-                acc = 0.f;
-                cur = c;
+        for (int r = r_lo + ry; r < r_hi; r += RG * U) {
+            float v[U];
+            int c[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {           // all loads of the group in flight together
+                const int rr = r + u * RG;
+                const bool ok = rr < r_hi;
+                v[u] = ok ? J.src[(long long)rr * J.H + h] : 0.f;
+                c[u] = ok ? (J.dWc ? J.cond[rr] : 0) : cur;
             }
-            acc += J.src[(long long)r * J.H + h];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (c[u] != cur) {
+                    if (cur >= 0) atomicAdd(&seg[cur * TAIL_COLS + cx], acc);
+                    acc = 0.f;
+                    cur = c[u];
+                }
+                acc += v[u];
+            }
         }
         if (cur >= 0) atomicAdd(&seg[cur * TAIL_COLS + cx], acc);
     }

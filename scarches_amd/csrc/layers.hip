@@ -204,7 +204,57 @@ struct LatentArgs {
     float* kl_row;                                       // [B]
 };
 
-__global__ __launch_bounds__(256) void latent_fwd_kernel(const LatentArgs a) {
+// One thread per (row, latent dim): coalesced over the [B][2Z] head rows; the row's KL is reduced across the Z
+// neighbouring lanes through LDS (a workgroup owns 256 / Zp whole rows, Zp = Z rounded up to a power of two).
+__global__ __launch_bounds__(256) void latent_fwd_kernel(const LatentArgs a, int Zp) {
+    __shared__ float klp[256];
+    const int Z = a.Z;
+    const int rows_per_blk = 256 / Zp;
+    const int rl = threadIdx.x / Zp, k = threadIdx.x - rl * Zp;
+    const int b = blockIdx.x * rows_per_blk + rl;
+    const bool act = rl < rows_per_blk && b < a.B && k < Z;
+    float kl = 0.f;
+    if (act) {
+        const uint32_t stp = a.step ? a.step[0] : 0u;
+        float mu = a.bias ? a.bias[k] : 0.f, lv = a.bias ? a.bias[Z + k] : 0.f;
+        for (int s = 0; s < a.S; ++s) {
+            const float* p = a.heads + s * a.slab_stride + (long long)b * 2 * Z;
+            mu += p[k];
+            lv += p[Z + k];
+        }
+        const float var = expf(lv) + 1e-4f;
+        const float sd = sqrtf(var);
+        float e = 0.f;
+        if (a.sample) {
+            if (a.eps) {
+                e = a.eps[(long long)b * Z + k];
+            } else {
+                float n0, n1;
+                philox_normal2(a.seed + stp, a.rng_stream, (uint32_t)(b * ((Z + 1) / 2) + (k >> 1)), n0, n1);
+                e = (k & 1) ? n1 : n0;
+            }
+        }
+        const float var_ratio = sd * sd;       // torch kl_normal_normal squares the scale again
+        kl = 0.5f * (var_ratio + mu * mu - 1.0f - logf(var_ratio));
+        if (a.mu_lv) {
+            a.mu_lv[(long long)b * 2 * Z + k] = mu;
+            a.mu_lv[(long long)b * 2 * Z + Z + k] = lv;
+        }
+        if (a.eps_out) a.eps_out[(long long)b * Z + k] = e;
+        a.z[(long long)b * Z + k] = fmaf(e, sd, mu);
+    }
+    if (!a.kl_row) return;
+    klp[threadIdx.x] = kl;
+    __syncthreads();
+    if (act && k == 0) {
+        float t = 0.f;
+        for (int q = 0; q < Z; ++q) t += klp[rl * Zp + q];      // same order as the per-row loop of the reference sum
+        a.kl_row[b] = t;
+    }
+}
+
+// Wide latents (Z > 256): one thread per row.
+__global__ __launch_bounds__(256) void latent_fwd_row_kernel(const LatentArgs a) {
     const int b = blockIdx.x * 256 + threadIdx.x;
     if (b >= a.B) return;
     const int Z = a.Z;
@@ -229,7 +279,7 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const LatentArgs a) {
                 e = (k & 1) ? n1 : n0;
             }
         }
-        const float var_ratio = sd * sd;       // torch kl_normal_normal squares the scale again
+        const float var_ratio = sd * sd;
         kl += 0.5f * (var_ratio + mu * mu - 1.0f - logf(var_ratio));
         if (a.mu_lv) {
             a.mu_lv[(long long)b * 2 * Z + k] = mu;
@@ -331,7 +381,14 @@ extern "C" int sca_latent_fwd(const float* heads, int S, long long slab_stride, 
                               float* mu_lv, float* eps_out, float* z, float* kl_row, void* stream) {
     if (B <= 0) return 0;
     LatentArgs a{heads, S, slab_stride, bias, B, Z, eps, seed, rng_stream, step, sample, mu_lv, eps_out, z, kl_row};
-    hipLaunchKernelGGL(latent_fwd_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    if (Z <= 256) {
+        int Zp = 1;
+        while (Zp < Z) Zp <<= 1;
+        const int rpb = 256 / Zp;
+        hipLaunchKernelGGL(latent_fwd_kernel, dim3((B + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, a, Zp);
+    } else {
+        hipLaunchKernelGGL(latent_fwd_row_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    }
     SCA_CHECK_LAUNCH();
     return 0;
 }

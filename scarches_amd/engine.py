@@ -473,14 +473,21 @@ class CVAEEngine:
         job of the tail kernel (instead of a sca_splitk_reduce launch per tensor)."""
         L = self.lib
         S = L.sca_gemm_splitk_heuristic(M, N, K)
+        rec = getattr(self, "record_gemms", None)
         if S == 1:
-            _lib.check(L.sca_gemm_f32(am, bm, A, lda, Bm, ldb, dst.data_ptr(), N, M, N, K, 1, 0, None, st), "gemm")
+            args = (am, bm, A, lda, Bm, ldb, dst.data_ptr(), N, M, N, K, 1, 0, None)
+            if rec is not None:
+                rec.append(args)
+            _lib.check(L.sca_gemm_f32(*args, st), "gemm")
             return
         key = "gslab:%d" % dst.data_ptr()
         slab = self.ws.get(key)
         if slab is None or slab.numel() < S * M * N:
             slab = self.ws[key] = torch.empty(S * M * N, dtype=torch.float32, device=self.device)
-        _lib.check(L.sca_gemm_f32(am, bm, A, lda, Bm, ldb, slab.data_ptr(), N, M, N, K, S, M * N, None, st), "gemm")
+        args = (am, bm, A, lda, Bm, ldb, slab.data_ptr(), N, M, N, K, S, M * N, None)
+        if rec is not None:
+            rec.append(args)
+        _lib.check(L.sca_gemm_f32(*args, st), "gemm")
         self._tail_jobs.append((0, S, M * N, slab.data_ptr(), dst.data_ptr(), M * N, 0, 0, 0, 0, 0))
 
     def _colsum(self, da, B, H, cond_p, C, dWc, db, st):
@@ -601,8 +608,10 @@ class CVAEEngine:
         self._ev_pro = self._flush()
         # 3. heads + sampling + KL
         Hl = self.H[-1]
-        sp, S, stride = self._gemm(0, 0, a, Hl, self.heads_w.data_ptr(), Hl, B, 2 * Z, Hl, st)
-        _lib.check(L.sca_latent_fwd(sp, S, stride, self.heads_b.data_ptr(), B, Z, ptr(eps), self.seed, 1, step_p, 1,
+        # heads: one [2*Zt, H] GEMM, bias fused, no split-K (K = H is short) -> the latent kernel reads one slab
+        self._gemm(0, 0, a, Hl, self.heads_w.data_ptr(), Hl, B, 2 * Z, Hl, st, out=ws["mu_lv"].data_ptr(),
+                   ldc=2 * Z, bias=self.heads_b.data_ptr(), force_s1=True)
+        _lib.check(L.sca_latent_fwd(ws["mu_lv"].data_ptr(), 1, 0, None, B, Z, ptr(eps), self.seed, 1, step_p, 1,
                                     ws["mu_lv"].data_ptr(), ws["eps"].data_ptr(), ws["z"].data_ptr(),
                                     ws["kl_row"].data_ptr(), st), "latent_fwd")
         # Side work is deferred: its dependency point is taken here, its launches are issued after the host has fed
@@ -631,6 +640,7 @@ class CVAEEngine:
             want_mmd()
         if self.cond_embed and proto is not None:
             self._n_part = self._launch_proto(proto, B, compute_grad)
+        ev_z = self._flush()         # MMD / prototype losses start now, beside the (small) decoder kernels
         if self.arch == "expimap":
             return self._expimap_tail(row_ids, cond_p, B, compute_grad, accumulate_logs, st)
         # 4. decoder
@@ -649,7 +659,7 @@ class CVAEEngine:
             self._gemm(0, 0, a, Hd, P["decoder.dropout_decoder.weight"].data_ptr(), Hd, B, G, Hd, st,
                        out=ws["pi"].data_ptr(), ldc=G, bias=P["decoder.dropout_decoder.bias"].data_ptr(),
                        force_s1=True)
-        ev_side = self._flush()
+        ev_side = self._flush() if self._aux_q else ev_z
         self._wait(self._ev_pro)
         # 6. reconstruction loss (+ gradient w.r.t. the logits, in place)
         rpb = max(1, B // 1024)
@@ -1024,11 +1034,13 @@ class CVAEEngine:
         buffers, so the launch sequence of a given batch size never changes.  It is recorded once and then either
           * "plan" : re-issued from the recorded (function, arguments) list - no Python work per launch besides the
                      ctypes call itself, launches stay in the hand-ordered main-first sequence;
-          * True   : replayed as HIP graphs (one graph launch per step; measured fastest at every batch size:
-                     0.25 / 0.32 / 0.50 / 2.03 ms at B = 128 / 1024 / 4096 / 16384 on MI355X) - the "auto" default;
+                     "auto" for B > 2048 (the HIP-graph executor re-orders independent branches - it starts the MMD
+                     beside the likelihood kernel instead of beside the small decoder kernels: 0.52 vs 0.49 ms);
+          * True   : replayed as HIP graphs (one graph launch per step; best when launch-bound: 0.27 ms at B=128
+                     against 0.37 ms eager) - "auto" for B <= 2048;
           * False  : launched eagerly through the normal Python path."""
         if use_graph == "auto":
-            use_graph = True
+            use_graph = True if B <= 2048 else "plan"
         self.begin_step(alpha_kl, lr, eps, clip)
         if use_graph is False:
             self.forward_backward(row_ids, cond, B)
