@@ -143,6 +143,34 @@ typedef struct {
 int sca_grad_tail_max_jobs(void);
 int sca_grad_tail(const sca_tail_job* jobs, int n_jobs, void* stream);
 
+/* ---- fused middle of the network ------------------------------------------------------------------------------
+ * Everything between the two wide GEMMs of a step in ONE launch per direction: the encoder layers after the first
+ * (modules.py:52-97), the fused mean / log-var heads, sampling + KL (_base.py:391-407, trvae.py:143-147) and the decoder
+ * hidden layers (modules.py:124-208), each with bias / one-hot condition column / LayerNorm / ReLU / dropout.  A
+ * workgroup walks the chain for a tile of 32 cells with activations in LDS.  sca_mid_fwd reads h_in [B][K0] (output of
+ * the first encoder layer) and writes every tensor the unfused kernels write (yn, rs, h per layer, mu_lv, eps, z,
+ * kl_row); sca_mid_bwd consumes the dX slabs of the output GEMM (dh, S, dh_stride) and optional dz2 [B][Z], writes the
+ * per-layer da, dheads and dh_out [B][K0] (gradient w.r.t. h_in).  Layer widths <= sca_mid_max_width().  `a` is a HOST
+ * struct (copied into the kernel arguments). */
+typedef struct {
+    const float* W; const float* bias; const float* Wc; const uint8_t* mask;
+    float* yn; float* rs; float* h; float* da;
+    int32_t N, K; uint32_t rng_stream; int32_t pad;
+} sca_mid_layer;
+typedef struct {
+    sca_mid_layer enc[4]; sca_mid_layer dec[4];
+    int32_t n_enc, n_dec;
+    const float* Wh; const float* bh; const float* eps_in; float* mu_lv; float* eps_out; float* z; float* kl_row;
+    int32_t Z, Kh; uint32_t rng_latent; int32_t sample;
+    int32_t B, C; const int32_t* cond;
+    int32_t norm; float p; uint64_t seed; const uint32_t* step;
+    const float* h_in; int32_t K0, S;
+    const float* dh; long long dh_stride; const float* dz2; const float* hyper; float* dheads; float* dh_out;
+} sca_mid_args;
+int sca_mid_max_width(void);
+int sca_mid_fwd(const sca_mid_args* a, void* stream);
+int sca_mid_bwd(const sca_mid_args* a, void* stream);
+
 /* ---- BatchNorm1d variant of the layer block (use_bn=True) -------------------------------------------------------
  * nn.BatchNorm1d(affine=True) between Linear and ReLU (models/trvae/modules.py:79,146,161).  sca_bn_fwd takes the
  * pre-activation a [B][H] (sca_layer_fwd with norm=0, relu=0), overwrites it with xhat and writes

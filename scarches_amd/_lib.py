@@ -26,6 +26,26 @@ class TailJob(C.Structure):
                 ("B", C.c_int32), ("H", C.c_int32), ("C", C.c_int32), ("pad", C.c_int32)]
 
 
+class MidLayer(C.Structure):
+    """sca_mid_layer of include/scarches_hip.h."""
+    _fields_ = [("W", C.c_void_p), ("bias", C.c_void_p), ("Wc", C.c_void_p), ("mask", C.c_void_p),
+                ("yn", C.c_void_p), ("rs", C.c_void_p), ("h", C.c_void_p), ("da", C.c_void_p),
+                ("N", C.c_int32), ("K", C.c_int32), ("rng_stream", C.c_uint32), ("pad", C.c_int32)]
+
+
+class MidArgs(C.Structure):
+    """sca_mid_args of include/scarches_hip.h."""
+    _fields_ = [("enc", MidLayer * 4), ("dec", MidLayer * 4), ("n_enc", C.c_int32), ("n_dec", C.c_int32),
+                ("Wh", C.c_void_p), ("bh", C.c_void_p), ("eps_in", C.c_void_p), ("mu_lv", C.c_void_p),
+                ("eps_out", C.c_void_p), ("z", C.c_void_p), ("kl_row", C.c_void_p),
+                ("Z", C.c_int32), ("Kh", C.c_int32), ("rng_latent", C.c_uint32), ("sample", C.c_int32),
+                ("B", C.c_int32), ("C", C.c_int32), ("cond", C.c_void_p),
+                ("norm", C.c_int32), ("p", C.c_float), ("seed", C.c_uint64), ("step", C.c_void_p),
+                ("h_in", C.c_void_p), ("K0", C.c_int32), ("S", C.c_int32),
+                ("dh", C.c_void_p), ("dh_stride", C.c_longlong), ("dz2", C.c_void_p), ("hyper", C.c_void_p),
+                ("dheads", C.c_void_p), ("dh_out", C.c_void_p)]
+
+
 # name -> argtypes (restype is always int); mirrors include/scarches_hip.h one to one
 SIGNATURES = {
     "sca_abi_version": [],
@@ -57,6 +77,9 @@ SIGNATURES = {
     "sca_prox_group_lasso": [P, I, I, F, P, P],
     "sca_hsic_workspace_floats": [I],
     "sca_hsic_fwd_bwd": [P, I, I, I, P, F, F, F, P, P, P, I, P, I, P],
+    "sca_mid_max_width": [],
+    "sca_mid_fwd": [P, P],
+    "sca_mid_bwd": [P, P],
     "sca_grad_tail_max_jobs": [],
     "sca_grad_tail": [P, I, P],
     "sca_bn_fwd": [P, I, I, P, P, P, P, I, I, F, F, P, U64, U32, P, P, P, P, P],

@@ -1,0 +1,585 @@
+// Fused middle of the conditional VAE (gfx950): everything between the two wide GEMMs of a step, one launch per
+// direction.
+//
+// For G >> H the network is two wide layers (genes -> H, H -> genes) around a chain of narrow ones: the remaining
+// encoder layers, the mean / log-var heads, the reparameterised sample + KL, and the decoder layers
+// (scarches/models/trvae/modules.py:52-97 Encoder, :124-208 Decoder, models/base/_base.py:391-407 sampling,
+// models/trvae/trvae.py:143-147 KL).  As separate GEMM + epilogue launches that chain is ~16 launches of a few us
+// each in both directions - launch- and latency-bound, a third of the step at B = 4096.  Here a workgroup owns a tile of
+// 32 cells and walks the whole chain with the activations in LDS: weights stream through LDS in 32-deep chunks, each
+// thread keeps a 4x4 register tile (fp32 FMA; the vector and matrix fp32 peaks of this part are equal), the row-wise
+// epilogues (bias, condition column, LayerNorm, ReLU, dropout; their backward) are the ones of layers.hip.
+// Everything the backward pass and the weight-gradient GEMMs need (normalised pre-activations, rstd, activations,
+// mean / log-var, noise, z, per-layer `da`) is still written to HBM; only the re-reads and the launches disappear.
+#include "common.h"
+
+extern "C" {
+typedef struct {
+    const float* W;        // [N][K]
+    const float* bias;     // [N] or NULL
+    const float* Wc;       // [N][C] one-hot condition weights or NULL
+    const uint8_t* mask;   // optional injected dropout keep-mask [B][N]
+    float* yn;             // [B][N] normalised pre-activation (saved by forward, read by backward)
+    float* rs;             // [B]
+    float* h;              // [B][N] layer output
+    float* da;             // [B][N] backward: gradient w.r.t. the Linear output
+    int32_t N, K;
+    uint32_t rng_stream;
+    int32_t pad;
+} sca_mid_layer;
+
+typedef struct {
+    sca_mid_layer enc[4];  // encoder layers AFTER the first one
+    sca_mid_layer dec[4];  // decoder hidden layers (first one carries Wc)
+    int32_t n_enc, n_dec;
+    const float* Wh;       // fused heads [2Z][Kh] = [mean | log_var]
+    const float* bh;       // [2Z]
+    const float* eps_in;   // optional injected noise [B][Z]
+    float* mu_lv;          // [B][2Z]
+    float* eps_out;        // [B][Z]
+    float* z;              // [B][Z]
+    float* kl_row;         // [B]
+    int32_t Z, Kh;
+    uint32_t rng_latent;
+    int32_t sample;
+    int32_t B, C;
+    const int32_t* cond;   // [B]
+    int32_t norm;          // 0 none, 1 LayerNorm
+    float p;               // dropout rate
+    uint64_t seed;
+    const uint32_t* step;
+    const float* h_in;     // [B][K0] output of the first encoder layer
+    int32_t K0, S;
+    // backward only
+    const float* dh;       // [S][B][N_last] slabs of d loss / d (last decoder layer output)
+    long long dh_stride;
+    const float* dz2;      // optional extra gradient w.r.t. z [B][Z] (MMD)
+    const float* hyper;    // hyper[0] = alpha_kl
+    float* dheads;         // [B][2Z]
+    float* dh_out;         // [B][K0] gradient w.r.t. h_in
+} sca_mid_args;
+}
+
+#ifdef SCA_MID_DEBUG
+__device__ long long g_mid_dbg[64];
+#define DBG(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_mid_dbg[i] = wall_clock64(); } while (0)
+#else
+#define DBG(i)
+#endif
+
+namespace {
+
+constexpr int TM = 32;          // cells per workgroup
+constexpr int KC = 64;          // reduction chunk staged in LDS (64 deep: half as many exposed weight-fetch latencies)
+constexpr int MS_LD = 129;      // leading dim of the staged weight chunk [KC][128] (+1: conflict-free transposed store)
+constexpr int MAXW = 256;       // widest supported layer
+constexpr int NST = KC * 128 / 256;   // staged weight values per thread and chunk
+
+// out[r][j] = sum_i act[r][i] * M(i, j), r < TM, j < J, i < I.
+//   FWD : M(i, j) = W[j*ldW + i]   (y = x W^T: i = input feature, j = output unit)
+//   !FWD: M(i, j) = W[i*ldW + j]   (dx = da W: i = output unit, j = input feature)
+template <bool FWD>
+__device__ __forceinline__ void stage_load(float (&v)[NST], const float* __restrict__ W, int ldW, int i0, int in_,
+                                           int j0, int jn) {
+    const int tid = threadIdx.x;
+    if (FWD) {
+        const int ii = tid & (KC - 1);
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            const int jj = tid / KC + (256 / KC) * q;
+            v[q] = (ii < in_ && jj < jn) ? W[(long long)(j0 + jj) * ldW + i0 + ii] : 0.f;
+        }
+    } else {
+        const int jj = tid & 127;
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            const int ii = (tid >> 7) + 2 * q;
+            v[q] = (ii < in_ && jj < jn) ? W[(long long)(i0 + ii) * ldW + j0 + jj] : 0.f;
+        }
+    }
+}
+
+template <bool FWD>
+__device__ __forceinline__ void stage_store(const float (&v)[NST], float* __restrict__ Ms) {
+    const int tid = threadIdx.x;
+    if (FWD) {
+        const int ii = tid & (KC - 1);
+#pragma unroll
+        for (int q = 0; q < NST; ++q) Ms[ii * MS_LD + tid / KC + (256 / KC) * q] = v[q];
+    } else {
+        const int jj = tid & 127;
+#pragma unroll
+        for (int q = 0; q < NST; ++q) Ms[((tid >> 7) + 2 * q) * MS_LD + jj] = v[q];
+    }
+}
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// One v_mfma_f32_32x32x2_f32 output block per wave: wave w owns columns [32w, 32w+32) of the current 128-column block,
+// all TM = 32 rows.  Operand layout of the instruction: A lane (l31, half) = act[l31][k + half], B lane (l31, half) =
+// M(k + half, l31); accumulator register r of lane (l31, half) = out[(r & 3) + 8 (r >> 2) + 4 half][l31].
+template <bool FWD>
+__device__ __forceinline__ void tile_gemm(const float* __restrict__ act, int lda, int I, const float* __restrict__ W,
+                                          int ldW, int J, float* __restrict__ out, int ldo, float* __restrict__ Ms) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+    for (int j0 = 0; j0 < J; j0 += 128) {
+        const int jn = min(128, J - j0);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        float nxt[NST];                             // next weight chunk, in flight while the current one is consumed
+        stage_load<FWD>(nxt, W, ldW, 0, min(KC, I), j0, jn);
+        for (int i0 = 0; i0 < I; i0 += KC) {
+            __syncthreads();                         // previous chunk consumed (and `act` complete on first entry)
+            stage_store<FWD>(nxt, Ms);
+            __syncthreads();
+            if (i0 + KC < I) stage_load<FWD>(nxt, W, ldW, i0 + KC, min(KC, I - i0 - KC), j0, jn);
+            const float* ap = act + l31 * lda + i0 + half;
+            const float* bp = Ms + half * MS_LD + 32 * w + l31;
+            float av[KC / 2], bv[KC / 2];
+#pragma unroll
+            for (int kk = 0; kk < KC / 2; ++kk) {
+                av[kk] = ap[2 * kk];
+                bv[kk] = bp[2 * kk * MS_LD];
+            }
+#pragma unroll
+            for (int kk = 0; kk < KC / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
+        }
+        const int n = 32 * w + l31;
+        if (n < jn) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2) + 4 * half) * ldo + j0 + n] = acc[r];
+        }
+    }
+    __syncthreads();
+}
+
+// act tiles are [TM][ld] with ld = round_up(width, KC) + 1 (conflict-free fragment reads); columns past the layer width must read as zero for the
+// K-chunk loop above, so every producer of a tile zero-fills up to the next multiple of KC.
+
+// 4 dropout keep decisions of columns col4 .. col4+3 (col4 % 4 == 0) from ONE Philox call - same bits as dropout_keep.
+__device__ __forceinline__ void dropout_keep4(uint64_t seed, uint32_t stream, uint32_t row, uint32_t col4, float p,
+                                              bool (&k)[4]) {
+    const Philox4 r = philox4x32_10(row, col4 >> 2, stream, 0x5ca1ab1eu, (uint32_t)seed, (uint32_t)(seed >> 32));
+    k[0] = u32_to_unit(r.x) > p; k[1] = u32_to_unit(r.y) > p; k[2] = u32_to_unit(r.z) > p; k[3] = u32_to_unit(r.w) > p;
+}
+
+__device__ __forceinline__ float row8_sum(float v) {      // sum over the 8 consecutive lanes that share a row
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
+// Copy a [TM][width] row-major HBM tile into LDS (zero padded to Kp columns, rows past B read as zero); 16-byte loads
+// when the row pitch allows it.  `S` slabs `stride` apart are summed on the way in.
+__device__ __forceinline__ void load_tile(float* __restrict__ dst, int ld, const float* __restrict__ src, int S,
+                                          long long stride, int r0, int B, int width, int Kp) {
+    if ((width & 3) == 0 && ((uintptr_t)src & 15) == 0 && (stride & 3) == 0) {
+        const int w4 = Kp >> 2;
+        for (int t = threadIdx.x; t < TM * w4; t += 256) {
+            const int r = t / w4, k = (t - r * w4) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < width && r0 + r < B) {
+                const float* p = src + (long long)(r0 + r) * width + k;
+                v = *reinterpret_cast<const float4*>(p);
+                for (int q = 1; q < S; ++q) {
+                    const float4 u = *reinterpret_cast<const float4*>(p + q * stride);
+                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                }
+            }
+            float* d = dst + r * ld + k;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+        for (int t = threadIdx.x; t < TM * Kp; t += 256) {
+            const int r = t / Kp, k = t - r * Kp;
+            float v = 0.f;
+            if (k < width && r0 + r < B)
+                for (int q = 0; q < S; ++q) v += src[q * stride + (long long)(r0 + r) * width + k];
+            dst[r * ld + k] = v;
+        }
+    }
+}
+
+// Row epilogue of one layer (forward): pre -> (+bias, +Wc[:, c]) -> LayerNorm -> ReLU -> dropout.
+// 8 threads per row (all 32 rows of the tile in flight at once); thread t8 owns the 4-column groups 4 t8 + 32 q, so the
+// 8 threads of a row touch 128 contiguous bytes per group (16-byte HBM stores).  All HBM reads of the epilogue (bias,
+// condition column) are issued up front and the row lives in registers from then on: the chain is latency-bound, not
+// arithmetic-bound.
+template <int QM>
+__device__ __forceinline__ void layer_epilogue_fwd(const sca_mid_args& a, const sca_mid_layer& L, const float* pre,
+                                                   float* nxt, int ld, int r0) {
+    const int row = threadIdx.x >> 3, t8 = threadIdx.x & 7;
+    const int N = L.N, Npad = ((N + KC - 1) / KC) * KC;
+    const int b = r0 + row;
+    const bool live = b < a.B;
+    const int c = (live && L.Wc) ? a.cond[b] : 0;
+    const bool vec = (N & 3) == 0 && ((((uintptr_t)L.yn | (uintptr_t)L.h) & 15) == 0);
+    const float* prow = pre + row * ld;
+    float v[QM][4];
+#pragma unroll
+    for (int q = 0; q < QM; ++q)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int hh = 32 * q + 4 * t8 + u;
+            float add = 0.f;
+            if (hh < N && live) {
+                if (L.bias) add = L.bias[hh];
+                if (L.Wc) add += L.Wc[(long long)hh * a.C + c];
+            }
+            v[q][u] = add;
+        }
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < QM; ++q)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int hh = 32 * q + 4 * t8 + u;
+            v[q][u] = (hh < N && live) ? v[q][u] + prow[hh] : 0.f;
+            sum += v[q][u];
+        }
+    float mean = 0.f, rs = 1.f;
+    if (a.norm == 1) {
+        mean = row8_sum(sum) / (float)N;
+        float sq = 0.f;
+#pragma unroll
+        for (int q = 0; q < QM; ++q)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (32 * q + 4 * t8 + u < N) {
+                    const float d = v[q][u] - mean;
+                    sq = fmaf(d, d, sq);
+                }
+        rs = 1.0f / sqrtf(row8_sum(sq) / (float)N + 1e-5f);
+    }
+    if (t8 == 0 && live) L.rs[b] = rs;
+    const float keep_scale = a.p > 0.f ? 1.0f / (1.0f - a.p) : 1.f;
+    const uint32_t stp = a.step ? a.step[0] : 0u;
+    float* nrow = nxt + row * ld;
+#pragma unroll
+    for (int q = 0; q < QM; ++q) {
+        const int h4 = 32 * q + 4 * t8;
+        if (h4 >= Npad) continue;
+        bool keep[4] = {true, true, true, true};
+        if (a.p > 0.f && live && !L.mask) dropout_keep4(a.seed + stp, L.rng_stream, (uint32_t)b, (uint32_t)h4, a.p, keep);
+        float yv[4], ov[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int hh = h4 + u;
+            yv[u] = ov[u] = 0.f;
+            if (hh < N && live) {
+                yv[u] = a.norm == 1 ? (v[q][u] - mean) * rs : v[q][u];
+                float o = fmaxf(yv[u], 0.f);
+                if (a.p > 0.f) {
+                    const bool kp = L.mask ? (L.mask[(long long)b * N + hh] != 0) : keep[u];
+                    o = kp ? o * keep_scale : 0.f;
+                }
+                ov[u] = o;
+            }
+            nrow[hh] = ov[u];
+        }
+        if (live) {
+            const long long g = (long long)b * N + h4;
+            if (vec) {
+                if (h4 < N) {
+                    *reinterpret_cast<float4*>(L.yn + g) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+                    *reinterpret_cast<float4*>(L.h + g) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (h4 + u < N) { L.yn[g + u] = yv[u]; L.h[g + u] = ov[u]; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void mid_fwd_kernel(const sca_mid_args a, int ld) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* A0 = smem;                  // [TM][ld]
+    float* A1 = A0 + TM * ld;          // [TM][ld]
+    float* Ms = A1 + TM * ld;          // [KC][MS_LD]
+    const int r0 = blockIdx.x * TM;
+    // input tile (zero padded to a multiple of KC columns)
+    load_tile(A0, ld, a.h_in, 1, 0, r0, a.B, a.K0, ((a.K0 + KC - 1) / KC) * KC);
+    float* cur = A0;
+    float* oth = A1;
+    DBG(0);
+    for (int l = 0; l < a.n_enc; ++l) {
+        const sca_mid_layer& L = a.enc[l];
+        tile_gemm<true>(cur, ld, L.K, L.W, L.K, L.N, oth, ld, Ms);
+        DBG(1);
+        layer_epilogue_fwd<2 * NS>(a, L, oth, cur, ld, r0);
+        DBG(2);
+    }
+    // heads + reparameterised sample + KL
+    const int Z = a.Z;
+    tile_gemm<true>(cur, ld, a.Kh, a.Wh, a.Kh, 2 * Z, oth, ld, Ms);
+    DBG(3);
+    {
+        const int Zp = ((Z + KC - 1) / KC) * KC;
+        const uint32_t stp = a.step ? a.step[0] : 0u;
+        for (int t = threadIdx.x; t < TM * (Zp - Z); t += 256) {          // zero padding of the z tile
+            const int r = t / (Zp - Z), k = Z + t - r * (Zp - Z);
+            cur[r * ld + k] = 0.f;
+        }
+        for (int t = threadIdx.x; t < TM * Z; t += 256) {
+            const int r = t / Z, k = t - r * Z, b = r0 + r;
+            float zv = 0.f, kl = 0.f;
+            if (b < a.B) {
+                const float mu = oth[r * ld + k] + a.bh[k], lv = oth[r * ld + Z + k] + a.bh[Z + k];
+                const float var = expf(lv) + 1e-4f, sd = sqrtf(var);
+                float e = 0.f;
+                if (a.sample) {
+                    if (a.eps_in) {
+                        e = a.eps_in[(long long)b * Z + k];
+                    } else {
+                        float n0, n1;
+                        philox_normal2(a.seed + stp, a.rng_latent, (uint32_t)(b * ((Z + 1) / 2) + (k >> 1)), n0, n1);
+                        e = (k & 1) ? n1 : n0;
+                    }
+                }
+                const float vr = sd * sd;
+                kl = 0.5f * (vr + mu * mu - 1.0f - logf(vr));
+                a.mu_lv[(long long)b * 2 * Z + k] = mu;
+                a.mu_lv[(long long)b * 2 * Z + Z + k] = lv;
+                a.eps_out[(long long)b * Z + k] = e;
+                zv = fmaf(e, sd, mu);
+                a.z[(long long)b * Z + k] = zv;
+            }
+            cur[r * ld + k] = zv;
+            oth[r * ld + 2 * Z + k] = kl;                 // parked next to the head outputs, summed below
+        }
+        __syncthreads();
+        for (int r = threadIdx.x; r < TM; r += 256)
+            if (r0 + r < a.B) {
+                float t = 0.f;
+                for (int k = 0; k < Z; ++k) t += oth[r * ld + 2 * Z + k];
+                a.kl_row[r0 + r] = t;
+            }
+        __syncthreads();
+    }
+    DBG(4);
+    for (int l = 0; l < a.n_dec; ++l) {
+        const sca_mid_layer& L = a.dec[l];
+        tile_gemm<true>(cur, ld, L.K, L.W, L.K, L.N, oth, ld, Ms);
+        DBG(5 + 2 * l);
+        layer_epilogue_fwd<2 * NS>(a, L, oth, cur, ld, r0);
+        DBG(6 + 2 * l);
+    }
+}
+
+// Row epilogue of one layer (backward): upstream gradient tile `g` -> dropout / ReLU / LayerNorm backward -> da
+// (HBM + tile `dst`, zero padded).  Same thread layout as the forward epilogue; the saved normalised pre-activations
+// are fetched from HBM up front.
+template <int QM>
+__device__ __forceinline__ void layer_epilogue_bwd(const sca_mid_args& a, const sca_mid_layer& L, const float* g,
+                                                   float* dst, int ld, int r0) {
+    const int row = threadIdx.x >> 3, t8 = threadIdx.x & 7;
+    const int N = L.N, Npad = ((N + KC - 1) / KC) * KC;
+    const int b = r0 + row;
+    const bool live = b < a.B;
+    const bool vec = (N & 3) == 0 && ((((uintptr_t)L.yn | (uintptr_t)L.da) & 15) == 0);
+    const float keep_scale = a.p > 0.f ? 1.0f / (1.0f - a.p) : 1.f;
+    const uint32_t stp = a.step ? a.step[0] : 0u;
+    const float* grow = g + row * ld;
+    float* drow = dst + row * ld;
+    float x[QM][4], y[QM][4];
+#pragma unroll
+    for (int q = 0; q < QM; ++q) {
+        const int h4 = 32 * q + 4 * t8;
+        const long long o = (long long)b * N + h4;
+        if (vec) {
+            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (h4 < N && live) t = *reinterpret_cast<const float4*>(L.yn + o);
+            y[q][0] = t.x; y[q][1] = t.y; y[q][2] = t.z; y[q][3] = t.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) y[q][u] = (h4 + u < N && live) ? L.yn[o + u] : 0.f;
+        }
+    }
+    const float rsv = (a.norm == 1 && live) ? L.rs[b] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < QM; ++q) {
+        const int h4 = 32 * q + 4 * t8;
+        bool keep[4] = {true, true, true, true};
+        if (a.p > 0.f && live && !L.mask && h4 < N)
+            dropout_keep4(a.seed + stp, L.rng_stream, (uint32_t)b, (uint32_t)h4, a.p, keep);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int hh = h4 + u;
+            float xv = 0.f;
+            if (hh < N && live) {
+                xv = grow[hh];
+                if (a.p > 0.f) {
+                    const bool kp = L.mask ? (L.mask[(long long)b * N + hh] != 0) : keep[u];
+                    xv = kp ? xv * keep_scale : 0.f;
+                }
+                if (!(y[q][u] > 0.f)) xv = 0.f;
+            }
+            x[q][u] = xv;
+            s1 += xv;
+            s2 = fmaf(xv, y[q][u], s2);
+        }
+    }
+    float m1 = 0.f, m2 = 0.f;
+    if (a.norm == 1) {
+        m1 = row8_sum(s1) / (float)N;
+        m2 = row8_sum(s2) / (float)N;
+    }
+#pragma unroll
+    for (int q = 0; q < QM; ++q) {
+        const int h4 = 32 * q + 4 * t8;
+        if (h4 >= Npad) continue;
+        float ov[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ov[u] = 0.f;
+            if (h4 + u < N && live) ov[u] = a.norm == 1 ? rsv * (x[q][u] - m1 - y[q][u] * m2) : x[q][u];
+            drow[h4 + u] = ov[u];
+        }
+        if (live) {
+            const long long o = (long long)b * N + h4;
+            if (vec) {
+                if (h4 < N) *reinterpret_cast<float4*>(L.da + o) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (h4 + u < N) L.da[o + u] = ov[u];
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void mid_bwd_kernel(const sca_mid_args a, int ld) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* A0 = smem;
+    float* A1 = A0 + TM * ld;
+    float* Ms = A1 + TM * ld;
+    const int r0 = blockIdx.x * TM;
+    const int Z = a.Z;
+    // upstream gradient tile: sum of the dX slabs of the output GEMM
+    {
+        const int N = a.n_dec ? a.dec[a.n_dec - 1].N : Z;
+        load_tile(A0, ld, a.dh, a.S, a.dh_stride, r0, a.B, N, N);
+        __syncthreads();
+    }
+    float* cur = A0;
+    float* oth = A1;
+    for (int l = a.n_dec - 1; l >= 0; --l) {
+        const sca_mid_layer& L = a.dec[l];
+        layer_epilogue_bwd<2 * NS>(a, L, cur, oth, ld, r0);               // oth = da [TM][N]
+        tile_gemm<false>(oth, ld, L.N, L.W, L.K, L.K, cur, ld, Ms);       // cur = dX [TM][K]
+    }
+    // latent block: dz (+ dz2) + KL -> d[mean | log_var]
+    {
+        const float akl = a.hyper[0] / (float)a.B;
+        const int Hp = ((2 * Z + KC - 1) / KC) * KC;
+        for (int t = threadIdx.x; t < TM * (Hp - 2 * Z); t += 256) {      // zero padding of the d-heads tile
+            const int r = t / (Hp - 2 * Z), k = 2 * Z + t - r * (Hp - 2 * Z);
+            oth[r * ld + k] = 0.f;
+        }
+        for (int t = threadIdx.x; t < TM * 2 * Z; t += 256) {
+            const int r = t / (2 * Z), k = t - r * 2 * Z, b = r0 + r;
+            float o = 0.f;
+            if (b < a.B) {
+                const int kk = k < Z ? k : k - Z;
+                float g = cur[r * ld + kk];
+                if (a.dz2) g += a.dz2[(long long)b * Z + kk];
+                const float mu = a.mu_lv[(long long)b * 2 * Z + kk], lv = a.mu_lv[(long long)b * 2 * Z + Z + kk];
+                const float ev = expf(lv), var = ev + 1e-4f, sd = sqrtf(var);
+                o = k < Z ? g + akl * mu
+                          : g * a.eps_out[(long long)b * Z + kk] * (0.5f * ev / sd) + akl * 0.5f * (1.0f - 1.0f / var) * ev;
+                a.dheads[(long long)b * 2 * Z + k] = o;
+            }
+            oth[r * ld + k] = o;
+        }
+        // tile_gemm starts with a barrier
+        tile_gemm<false>(oth, ld, 2 * Z, a.Wh, a.Kh, a.Kh, cur, ld, Ms);  // cur = d h_enc_last [TM][Kh]
+    }
+    for (int l = a.n_enc - 1; l >= 0; --l) {
+        const sca_mid_layer& L = a.enc[l];
+        layer_epilogue_bwd<2 * NS>(a, L, cur, oth, ld, r0);
+        tile_gemm<false>(oth, ld, L.N, L.W, L.K, L.K, cur, ld, Ms);
+    }
+    if ((a.K0 & 3) == 0 && ((uintptr_t)a.dh_out & 15) == 0) {
+        const int w4 = a.K0 >> 2;
+        for (int t = threadIdx.x; t < TM * w4; t += 256) {
+            const int r = t / w4, k = (t - r * w4) * 4;
+            const float* p = cur + r * ld + k;
+            if (r0 + r < a.B)
+                *reinterpret_cast<float4*>(a.dh_out + (long long)(r0 + r) * a.K0 + k) = make_float4(p[0], p[1], p[2], p[3]);
+        }
+    } else {
+        for (int t = threadIdx.x; t < TM * a.K0; t += 256) {
+            const int r = t / a.K0, k = t - r * a.K0;
+            if (r0 + r < a.B) a.dh_out[(long long)(r0 + r) * a.K0 + k] = cur[r * ld + k];
+        }
+    }
+}
+
+int check_and_ld(const sca_mid_args* a, int* ld, size_t* shm, int* wide) {
+    if (a->B <= 0) return 1;
+    if (a->n_enc < 0 || a->n_enc > 4 || a->n_dec < 0 || a->n_dec > 4) return -1;
+    int maxw = a->K0 > a->Kh ? a->K0 : a->Kh;
+    if (3 * a->Z > maxw) maxw = 3 * a->Z;
+    for (int l = 0; l < a->n_enc; ++l) { if (a->enc[l].N > maxw) maxw = a->enc[l].N; if (a->enc[l].K > maxw) maxw = a->enc[l].K; }
+    for (int l = 0; l < a->n_dec; ++l) { if (a->dec[l].N > maxw) maxw = a->dec[l].N; if (a->dec[l].K > maxw) maxw = a->dec[l].K; }
+    if (maxw > MAXW) return -2;
+    int maxn = 0;
+    for (int l = 0; l < a->n_enc; ++l) if (a->enc[l].N > maxn) maxn = a->enc[l].N;
+    for (int l = 0; l < a->n_dec; ++l) if (a->dec[l].N > maxn) maxn = a->dec[l].N;
+    *wide = maxn > 128;
+    *ld = ((maxw + KC - 1) / KC) * KC + 1;
+    *shm = sizeof(float) * ((size_t)2 * TM * (*ld) + (size_t)KC * MS_LD);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int sca_mid_max_width(void) { return MAXW; }
+
+#ifdef SCA_MID_DEBUG
+extern "C" int sca_mid_debug(long long* host64) {
+    return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(g_mid_dbg), sizeof(long long) * 64);
+}
+#endif
+
+extern "C" int sca_mid_fwd(const sca_mid_args* a, void* stream) {
+    int ld, wide; size_t shm;
+    const int rc = check_and_ld(a, &ld, &shm, &wide);
+    if (rc) return rc > 0 ? 0 : rc;
+    const dim3 grid((a->B + TM - 1) / TM);
+    if (wide) {
+        hipFuncSetAttribute((const void*)mid_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL(mid_fwd_kernel<4>, grid, dim3(256), shm, (hipStream_t)stream, *a, ld);
+    } else {
+        hipFuncSetAttribute((const void*)mid_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL(mid_fwd_kernel<2>, grid, dim3(256), shm, (hipStream_t)stream, *a, ld);
+    }
+    SCA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sca_mid_bwd(const sca_mid_args* a, void* stream) {
+    int ld, wide; size_t shm;
+    const int rc = check_and_ld(a, &ld, &shm, &wide);
+    if (rc) return rc > 0 ? 0 : rc;
+    if (!a->dh || !a->dheads || !a->dh_out || !a->hyper) return -1;
+    const dim3 grid((a->B + TM - 1) / TM);
+    if (wide) {
+        hipFuncSetAttribute((const void*)mid_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL(mid_bwd_kernel<4>, grid, dim3(256), shm, (hipStream_t)stream, *a, ld);
+    } else {
+        hipFuncSetAttribute((const void*)mid_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL(mid_bwd_kernel<2>, grid, dim3(256), shm, (hipStream_t)stream, *a, ld);
+    }
+    SCA_CHECK_LAUNCH();
+    return 0;
+}

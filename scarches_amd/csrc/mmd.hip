@@ -9,9 +9,10 @@
 //     mmd = sum_{i,j} Wt[c_i][c_j] * K(z_i, z_j),   Wt[a][b] = beta * Q[a][b] / (n_a n_b)
 //   with Q[a][a] = number of pairs containing a, Q[a][b] = -1 for each selected pair (SURVEY a18 identity).
 // The gradient d mmd / d z_i = 4 sum_j Wt[c_i][c_j] K'(d2_ij) (z_i - z_j) is accumulated in the same pass
-// (K' = -sum_alpha exp(-d2/2alpha) / (2 alpha)), written as per-column-chunk slabs (no atomics).
-// The kernel is order-agnostic (any row order); it is exp-throughput bound: 19 v_exp per pair.
+// (K' = -sum_alpha exp(-d2/2alpha) / (2 alpha)).  The kernels are order-agnostic (any row order) and bound by the
+// quarter-rate v_exp_f32; see rbf19 and mmd_small_kernel for how the exp count per ordered pair is cut from 19 to ~4.5.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -22,19 +23,66 @@ __constant__ float MMD_BETA[19] = {
     1.f / (2.f * 20.f),  1.f / (2.f * 25.f),  1.f / (2.f * 30.f),  1.f / (2.f * 35.f),  1.f / (2.f * 100.f),
     1.f / (2.f * 1e3f),  1.f / (2.f * 1e4f),  1.f / (2.f * 1e5f),  1.f / (2.f * 1e6f)};
 
-// Single workgroup: condition counts -> weight table Wt[C][C].
+// 1 / (2 alpha) as compile-time constants (for the straight-line code below; same values as MMD_BETA)
+__host__ __device__ constexpr float mmd_beta(int a) {
+    constexpr float alpha[19] = {1e-6f, 1e-5f, 1e-4f, 1e-3f, 1e-2f, 1e-1f, 1.f,  5.f,  10.f, 15.f,
+                                 20.f,  25.f,  30.f,  35.f,  100.f, 1e3f,  1e4f, 1e5f, 1e6f};
+    return 1.f / (2.f * alpha[a]);
+}
+// The five widest bandwidths (alpha >= 100, beta <= 0.005) as ONE polynomial in d2:
+//   sum_a exp(-beta_a d2) = sum_k (-d2)^k S_k / k!,  sum_a beta_a exp(-beta_a d2) = sum_k (-d2)^k S_{k+1} / k!,
+//   S_k = sum_a beta_a^k.  Degree 7 on d2 <= 64 (beta d2 <= 0.32): truncation < 3e-9 relative.
+constexpr int MMD_WIDE0 = 14;
+constexpr int MMD_POLY_DEG = 7;
+constexpr float MMD_POLY_MAX_D2 = 64.f;
+__host__ __device__ constexpr double mmd_wide_S(int k) {
+    double s = 0.0;
+    for (int a = MMD_WIDE0; a < 19; ++a) {
+        double p = 1.0;
+        for (int i = 0; i < k; ++i) p *= (double)mmd_beta(a);
+        s += p;
+    }
+    return s;
+}
+__host__ __device__ constexpr double mmd_fact(int k) { return k <= 1 ? 1.0 : k * mmd_fact(k - 1); }
+template <int K> struct MmdPoly {
+    static constexpr float cK = (float)(((K & 1) ? -1.0 : 1.0) * mmd_wide_S(K) / mmd_fact(K));
+    static constexpr float cP = (float)(((K & 1) ? -1.0 : 1.0) * mmd_wide_S(K + 1) / mmd_fact(K));
+};
+
+// Condition counts -> weight table Wt[C][C] (workgroup 0); the other workgroups clear `zero_buf` (the gradient
+// accumulator of the small-D kernel).  Counting walks contiguous segments so that condition-sorted minibatches cost
+// one LDS atomic per run, not one per cell.
 __global__ __launch_bounds__(256) void mmd_prepare_kernel(const int32_t* __restrict__ cond, int B, int C, int boundary,
                                                           float beta, float* __restrict__ Wt,
-                                                          int32_t* __restrict__ counts_out) {
+                                                          int32_t* __restrict__ counts_out,
+                                                          float* __restrict__ zero_buf, long long zero_n) {
+    if (blockIdx.x > 0) {
+        const long long i = ((long long)(blockIdx.x - 1) * 256 + threadIdx.x) * 4;
+        if (i + 3 < zero_n) *reinterpret_cast<float4*>(zero_buf + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+        else for (long long q = i; q < zero_n; ++q) zero_buf[q] = 0.f;
+        return;
+    }
     extern __shared__ int cnt[];           // [C] counts, then [C] valid flags
     int* valid = cnt + C;
     __shared__ int nlow, nhigh;
     for (int i = threadIdx.x; i < C; i += 256) cnt[i] = 0;
     if (threadIdx.x == 0) { nlow = 0; nhigh = 0; }
     __syncthreads();
-    for (int i = threadIdx.x; i < B; i += 256) {
-        const int c = cond[i];
-        if (c >= 0 && c < C) atomicAdd(&cnt[c], 1);
+    {
+        const int len = (B + 255) / 256;
+        const int lo = threadIdx.x * len, hi = min(B, lo + len);
+        int cur = -1, n = 0;
+        for (int i = lo; i < hi; ++i) {
+            const int c = cond[i];
+            if (c != cur) {
+                if (n > 0 && cur >= 0 && cur < C) atomicAdd(&cnt[cur], n);
+                cur = c;
+                n = 0;
+            }
+            ++n;
+        }
+        if (n > 0 && cur >= 0 && cur < C) atomicAdd(&cnt[cur], n);
     }
     __syncthreads();
     const int need = boundary >= 0 ? 2 : 1;
@@ -65,94 +113,229 @@ __global__ __launch_bounds__(256) void mmd_prepare_kernel(const int32_t* __restr
     }
 }
 
-// K = sum_a exp(-beta_a d2), Kp = sum_a beta_a exp(-beta_a d2) over the 19 bandwidths: straight-line code,
-// one v_mul + one raw v_exp_f32 (2^x; results below 2^-126 flush to 0, i.e. < 1.2e-38 absolute) + two accumulates
-// per bandwidth.  (Per-term wave-uniform skip branches were measured slower than the exps they save.)
-__device__ __forceinline__ void rbf19(float d2, float& K, float& Kp) {
+// K = sum_a exp(-beta_a d2), Kp = sum_a beta_a exp(-beta_a d2) over the 19 bandwidths.  The kernel is bound by the
+// quarter-rate v_exp_f32, so the 19 exps are cut with two wave-uniform shortcuts that leave the values unchanged
+// to fp32 rounding:
+//   * alpha <= 0.01 (beta >= 50): 2^(-beta log2e d2) flushes to exactly 0 once beta log2e d2 > 126, i.e. for every
+//     lane with d2 > 1.75 - one ballot skips the five exps (taken for all but near-coincident pairs);
+//   * alpha >= 100: the five widest kernels are one degree-7 polynomial pair while every lane has d2 <= 64.
+// The nine bandwidths in between take one v_mul + one raw v_exp_f32 (2^x) + two accumulates each.
+template <int U>
+__device__ __forceinline__ void rbf_terms(int a, const float (&d2)[U], float (&K)[U], float (&Kp)[U]) {
     constexpr float LOG2E = 1.4426950408889634f;
-    K = 0.f; Kp = 0.f;
+    const float beta = MMD_BETA[a];
 #pragma unroll
-    for (int a = 0; a < 19; ++a) {
-        const float beta = MMD_BETA[a];
-        const float e = __builtin_amdgcn_exp2f(-(beta * LOG2E) * d2);
-        K += e;
-        Kp = fmaf(beta, e, Kp);
+    for (int u = 0; u < U; ++u) {
+        const float e = __builtin_amdgcn_exp2f(-(beta * LOG2E) * d2[u]);
+        K[u] += e;
+        Kp[u] = fmaf(beta, e, Kp[u]);
     }
 }
+// U independent pairs per call: the per-pair chains (exp -> accumulate, Horner) are latency-bound on their own
+template <int U>
+__device__ __forceinline__ void rbf19(const float (&d2)[U], float (&K)[U], float (&Kp)[U]) {
+    bool near = false, far = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        K[u] = 0.f; Kp[u] = 0.f;
+        near |= d2[u] < 1.75f;
+        far |= d2[u] > MMD_POLY_MAX_D2;
+    }
+#pragma unroll
+    for (int a = 5; a < MMD_WIDE0; ++a) rbf_terms<U>(a, d2, K, Kp);
+    if (__ballot(near) != 0ull) {
+#pragma unroll
+        for (int a = 0; a < 5; ++a) rbf_terms<U>(a, d2, K, Kp);
+    }
+    if (__ballot(far) == 0ull) {
+        float k[U], p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { k[u] = MmdPoly<7>::cK; p[u] = MmdPoly<7>::cP; }
+#define MMD_HORNER(N)                                                                   \
+        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                 \
+            k[u] = fmaf(k[u], d2[u], MmdPoly<N>::cK);                                   \
+            p[u] = fmaf(p[u], d2[u], MmdPoly<N>::cP);                                   \
+        }
+        MMD_HORNER(6) MMD_HORNER(5) MMD_HORNER(4) MMD_HORNER(3) MMD_HORNER(2) MMD_HORNER(1) MMD_HORNER(0)
+#undef MMD_HORNER
+#pragma unroll
+        for (int u = 0; u < U; ++u) { K[u] += k[u]; Kp[u] += p[u]; }
+    } else {
+#pragma unroll
+        for (int a = MMD_WIDE0; a < 19; ++a) rbf_terms<U>(a, d2, K, Kp);
+    }
+}
+__device__ __forceinline__ void rbf19(float d2, float& K, float& Kp) {
+    const float d[1] = {d2};
+    float k[1], p[1];
+    rbf19<1>(d, k, p);
+    K = k[0]; Kp = p[0];
+}
 
-constexpr int MMD_JC = 64;    // columns (j) per workgroup chunk (== wave size: run ends come from one ballot)
+constexpr int MMD_T = 64;     // rows per wave (== wave size)
+constexpr int MMD_TC = 32;    // columns per workgroup chunk
+constexpr int MMD_PLD = 65;   // row pitch of the coefficient tile (conflict-free both ways)
 
-// Small feature dimension (latent z): z_i, diff and the gradient accumulator live in registers.
+// Small feature dimension (latent z): K(i,j) = K(j,i) and Wt is symmetric, so only tiles on or above the diagonal
+// are evaluated.  A wave owns 64 rows i (z_i, diff and the row gradient in registers) and walks the 32 columns of the
+// workgroup's chunk, four columns per iteration; for an off-diagonal tile the pair coefficient coef_ij = -4 Wt K' is
+// parked in LDS and a second, cheap pass with the roles swapped (lane = column, 2 lanes x D/2 features per column)
+// accumulates the column gradient  g_j = z_j sum_i coef_ij - sum_i coef_ij z_i, so every exp serves both ordered
+// pairs.  Column gradients are added into slab 0 of `grad` with float atomics (zeroed by mmd_prepare_kernel), once
+// per chunk after an LDS sum over the four waves; row gradients are plain stores into the slab of the workgroup's
+// column range (workgroups below the diagonal store zeros), so the consumer sums 1 + gridDim.y slabs.
 template <int DMAX>
 __global__ __launch_bounds__(256) void mmd_small_kernel(const float* __restrict__ z, int ldz,
                                                         const int32_t* __restrict__ cond, int B, int D, int C,
                                                         const float* __restrict__ Wt, double* __restrict__ loss_part,
-                                                        float* __restrict__ grad_slabs, long long slab_stride) {
-    __shared__ float zj[MMD_JC * DMAX];
-    __shared__ int cj[MMD_JC];
-    __shared__ int rend[MMD_JC];
+                                                        float* __restrict__ grad, long long slab_stride, int JR) {
+    constexpr int KH = (DMAX + 1) / 2;        // features per half-wave in the transposed pass
+    static_assert(KH <= 8, "transposed pass reads two float4 per row");
+    __shared__ __attribute__((aligned(16))) float zis[4][MMD_T * 16];   // [i][half*8 + q] = z_i[half*KH + q]
+    __shared__ float zj[MMD_TC * DMAX];
+    __shared__ int cj[MMD_TC];
+    __shared__ float Pt[4][MMD_TC * MMD_PLD];  // per wave: coef tile [column][row]; later the wave's column gradients
     __shared__ double redd[16];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int j0 = blockIdx.y * MMD_JC, j1 = min(B, j0 + MMD_JC);
-    for (int t = threadIdx.x; t < (j1 - j0) * D; t += 256) {
-        const int jj = t / D, k = t - jj * D;
-        zj[jj * DMAX + k] = z[(long long)(j0 + jj) * ldz + k];
-    }
-    for (int t = threadIdx.x; t < j1 - j0; t += 256) cj[t] = cond[j0 + t];
-    __syncthreads();
-    if (threadIdx.x < 64) {      // rend[t] = one past the end of t's condition run (MMD_JC == 64: one wave, one ballot)
-        const int t = threadIdx.x, n = j1 - j0;
-        const bool last = t < n && (t == n - 1 || cj[t + 1] != cj[t]);
-        const unsigned long long m = __ballot(last);
-        if (t < n) rend[t] = t + __ffsll((long long)(m >> t));
-    }
-    __syncthreads();
-
-    float zi[DMAX], gr[DMAX];
+    static_assert(MMD_TC * MMD_PLD >= MMD_TC * DMAX, "column-gradient staging aliases the coefficient tile");
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int nb = (B + MMD_T - 1) / MMD_T, nbc = (B + MMD_TC - 1) / MMD_TC;
+    constexpr int CPR = MMD_T / MMD_TC;        // column chunks per row block
+    const int Jend = min(nbc, ((int)blockIdx.y + 1) * JR);
+    const int Jbeg = max((int)blockIdx.y * JR, (int)blockIdx.x * 4 * CPR);
+    const int I = blockIdx.x * 4 + w;
+    const int i = I * MMD_T + lane;
     const bool act = i < B;
-    const int ci = act ? cond[i] : 0;
+    // row gradients go to the slab of this column range (slab 0 collects the column gradients)
+    float* gslab = grad ? grad + (1 + (long long)blockIdx.y) * slab_stride + (long long)i * D : nullptr;
+    if (Jbeg >= Jend) {                        // every tile of this workgroup lies below the diagonal
+        if (threadIdx.x == 0) loss_part[blockIdx.y * gridDim.x + blockIdx.x] = 0.0;
+        if (act && gslab)
+            for (int k = 0; k < D; ++k) gslab[k] = 0.f;
+        return;
+    }
+    const int ci = act ? cond[i] : -1;
+    const bool ok = ci >= 0 && ci < C;
+    const float* wrow = Wt + (long long)(ok ? ci : 0) * C;
+    float zi[DMAX], gr[DMAX];
 #pragma unroll
     for (int k = 0; k < DMAX; ++k) {
         zi[k] = (act && k < D) ? z[(long long)i * ldz + k] : 0.f;
         gr[k] = 0.f;
     }
-    const bool ci_ok = ci >= 0 && ci < C;
-    const float* wrow = Wt + (long long)(ci_ok ? ci : 0) * C;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float v = 0.f;
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k)
+                if (q < KH && k == h * KH + q) v = zi[k];
+            zis[w][lane * 16 + h * 8 + q] = v;
+        }
     float lsum = 0.f;
-    if (act && ci_ok) {
-        // columns are walked run by run (a run = consecutive columns of one condition; condition-sorted
-        // minibatches have <= C runs): the weight is fetched once per run and the inner loop is pure VALU + LDS
-        int jj = 0;
-        const int nj = j1 - j0;
-        while (jj < nj) {
-            const int c2 = __builtin_amdgcn_readfirstlane(cj[jj]);
-            const int je = __builtin_amdgcn_readfirstlane(rend[jj]);
-            const float w = (c2 >= 0 && c2 < C) ? wrow[c2] : 0.f;
-            for (; jj < je; ++jj) {
-                float diff[DMAX];
-                float d2 = 0.f;
+    const int jp = lane & (MMD_TC - 1), kh = lane >> 5;       // transposed pass: column of the chunk, feature half
+    for (int J = Jbeg; J < Jend; ++J) {
+        const int j0 = J * MMD_TC, nj = min(B - j0, MMD_TC);
+        __syncthreads();                       // previous chunk fully consumed
+        for (int t = threadIdx.x; t < nj * D; t += 256) {
+            const int jj = t / D, k = t - jj * D;
+            zj[jj * DMAX + k] = z[(long long)(j0 + jj) * ldz + k];
+        }
+        if (threadIdx.x < MMD_TC) cj[threadIdx.x] = threadIdx.x < nj ? cond[j0 + threadIdx.x] : -1;
+        __syncthreads();
+        // bit t of `ends` = column t closes a condition run (every wave derives it for itself: one ballot)
+        const unsigned long long ends =
+            __ballot(lane < nj && (lane == nj - 1 || cj[min(lane + 1, MMD_TC - 1)] != cj[min(lane, MMD_TC - 1)]));
+        const int Ij = J / CPR;                // row block the chunk's columns belong to
+        const bool mine = I <= Ij && I < nb;   // wave-uniform
+        const bool diag = I == Ij;
+        const bool park = mine && !diag && grad != nullptr;
+        float gj[KH];
 #pragma unroll
-                for (int k = 0; k < DMAX; ++k) {
-                    diff[k] = zi[k] - zj[jj * DMAX + k];     // k >= D: LDS pad is never read into the result
-                    if (k < D) d2 = fmaf(diff[k], diff[k], d2);
+        for (int q = 0; q < KH; ++q) gj[q] = 0.f;
+        if (mine) {
+            float wgt = 0.f, wl = 0.f, w4 = 0.f;
+            // U columns of one condition run: U independent diff -> d2 -> exp -> accumulate chains
+            auto columns = [&](auto UU, int jj) {
+                constexpr int U = decltype(UU)::value;
+                float diff[U][DMAX], d2[U], K[U], Kp[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    d2[u] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < DMAX; ++k) {
+                        diff[u][k] = zi[k] - zj[(jj + u) * DMAX + k];   // k >= D: LDS pad never reaches the result
+                        if (k < D) d2[u] = fmaf(diff[u][k], diff[u][k], d2[u]);
+                    }
                 }
-                float K, Kp;
-                rbf19(d2, K, Kp);
-                lsum = fmaf(w, K, lsum);
-                const float coef = -4.0f * w * Kp;
+                rbf19<U>(d2, K, Kp);
 #pragma unroll
-                for (int k = 0; k < DMAX; ++k)
-                    if (k < D) gr[k] = fmaf(coef, diff[k], gr[k]);
+                for (int u = 0; u < U; ++u) {
+                    lsum = fmaf(wl, K[u], lsum);
+                    const float coef = w4 * Kp[u];
+#pragma unroll
+                    for (int k = 0; k < DMAX; ++k)
+                        if (k < D) gr[k] = fmaf(coef, diff[u][k], gr[k]);
+                    if (park) Pt[w][(jj + u) * MMD_PLD + lane] = coef;
+                }
+            };
+            int jj = 0;
+            while (jj < nj) {
+                // columns are walked run by run (condition-sorted minibatches have few runs): the weight is fetched
+                // once per run and the inner loop is pure VALU + LDS
+                const int c2 = __builtin_amdgcn_readfirstlane(cj[jj]);
+                const int je = jj + __ffsll((long long)(ends >> jj));
+                wgt = (ok && c2 >= 0 && c2 < C) ? wrow[c2] : 0.f;
+                wl = diag ? wgt : 2.0f * wgt;
+                w4 = -4.0f * wgt;
+                for (; jj + 4 <= je; jj += 4) columns(std::integral_constant<int, 4>{}, jj);
+                for (; jj < je; ++jj) columns(std::integral_constant<int, 1>{}, jj);
+            }
+            if (park) {
+                // roles swapped: lane = (column jp, feature half kh); rows of this wave come from LDS
+                float csum = 0.f, acc[KH];
+#pragma unroll
+                for (int q = 0; q < KH; ++q) acc[q] = 0.f;
+                const float* prow = &Pt[w][jp * MMD_PLD];
+                const float* zr = &zis[w][kh * 8];
+#pragma unroll 8
+                for (int i2 = 0; i2 < MMD_T; ++i2) {
+                    const float c = prow[i2];
+                    const float4 a0 = *reinterpret_cast<const float4*>(zr + i2 * 16);
+                    const float4 a1 = *reinterpret_cast<const float4*>(zr + i2 * 16 + 4);
+                    const float zv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    csum += c;
+#pragma unroll
+                    for (int q = 0; q < KH; ++q) acc[q] = fmaf(c, zv[q], acc[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < KH; ++q) {
+                    const int k = kh * KH + q;
+                    gj[q] = (jp < nj && k < D) ? fmaf(zj[jp * DMAX + k], csum, -acc[q]) : 0.f;
+                }
+            }
+        }
+        if (grad != nullptr) {
+            // column gradients of the four waves: staged in each wave's own (now dead) coefficient tile, summed, added
+#pragma unroll
+            for (int q = 0; q < KH; ++q) {
+                const int k = kh * KH + q;
+                if (k < DMAX) Pt[w][jp * DMAX + k] = gj[q];
+            }
+            __syncthreads();
+            for (int t = threadIdx.x; t < nj * D; t += 256) {
+                const int jj = t / D, k = t - jj * D;
+                const float s = (Pt[0][jj * DMAX + k] + Pt[1][jj * DMAX + k]) + (Pt[2][jj * DMAX + k] + Pt[3][jj * DMAX + k]);
+                if (s != 0.f) atomicAdd(&grad[(long long)(j0 + jj) * D + k], s);
             }
         }
     }
     const double tot = block_sum_d((double)lsum, redd);
     if (threadIdx.x == 0) loss_part[blockIdx.y * gridDim.x + blockIdx.x] = tot;
-    if (act && grad_slabs) {
-        float* g = grad_slabs + blockIdx.y * slab_stride + (long long)i * D;
+    if (act && gslab) {
 #pragma unroll
         for (int k = 0; k < DMAX; ++k)
-            if (k < D) g[k] = gr[k];
+            if (k < D) gslab[k] = gr[k];
     }
 }
 
@@ -234,9 +417,21 @@ __global__ __launch_bounds__(256) void mmd_generic_kernel(const float* __restric
 
 }  // namespace
 
+// Column chunks per workgroup of the small-D kernel: about 1024 workgroups on or above the diagonal.
+static int mmd_small_jr(int B) {
+    const long long nb = (B + MMD_T - 1) / MMD_T, nbc = (B + MMD_TC - 1) / MMD_TC;
+    long long jr = ((nb + 3) / 4) * nbc / 2 / 1024;
+    if (jr < 1) jr = 1;
+    if (jr > 32) jr = 32;
+    return (int)jr;
+}
+
 // Number of gradient slabs / loss partials the main kernel will produce for (B, D).
 extern "C" int sca_mmd_num_slabs(int B, int D) {
-    if (D <= 16) return (B + MMD_JC - 1) / MMD_JC;
+    if (D <= 16) {                         // column-gradient accumulator + one row-gradient slab per column range
+        const int nbc = (B + MMD_TC - 1) / MMD_TC, jr = mmd_small_jr(B);
+        return 1 + (nbc + jr - 1) / jr;
+    }
     // generic kernel: aim for >= 512 workgroups
     const int itiles = (B + 15) / 16;
     int chunks = (512 + itiles - 1) / itiles;
@@ -246,7 +441,10 @@ extern "C" int sca_mmd_num_slabs(int B, int D) {
     return chunks;
 }
 extern "C" int sca_mmd_num_partials(int B, int D) {
-    if (D <= 16) return sca_mmd_num_slabs(B, D) * ((B + 255) / 256);
+    if (D <= 16) {
+        const int nb = (B + MMD_T - 1) / MMD_T, nbc = (B + MMD_TC - 1) / MMD_TC, jr = mmd_small_jr(B);
+        return ((nb + 3) / 4) * ((nbc + jr - 1) / jr);
+    }
     return sca_mmd_num_slabs(B, D) * ((B + 15) / 16);
 }
 
@@ -258,17 +456,21 @@ extern "C" int sca_mmd_fwd_bwd(const float* feat, int ld, const int32_t* cond, i
     if (B <= 0 || C <= 0) return 0;
     if (C > 4096 || D > 1024) return -2;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(mmd_prepare_kernel, dim3(1), dim3(256), 2 * C * sizeof(int), st, cond, B, C, boundary, beta, Wt,
-                       counts);
+    const bool small = D <= 16;
+    const long long zero_n = (small && grad_slabs) ? (long long)B * D : 0;
+    const int zero_wg = (int)((zero_n + 1023) / 1024);
+    hipLaunchKernelGGL(mmd_prepare_kernel, dim3(1 + zero_wg), dim3(256), 2 * C * sizeof(int), st, cond, B, C, boundary,
+                       beta, Wt, counts, grad_slabs, zero_n);
     const int ns = sca_mmd_num_slabs(B, D);
-    if (D <= 16) {
-        dim3 grid((B + 255) / 256, ns);
+    if (small) {
+        const int nb = (B + MMD_T - 1) / MMD_T, nbc = (B + MMD_TC - 1) / MMD_TC, jr = mmd_small_jr(B);
+        dim3 grid((nb + 3) / 4, (nbc + jr - 1) / jr);
         if (D == 10)        // the default latent width: exact-size instantiation, all k < D guards fold away
             hipLaunchKernelGGL((mmd_small_kernel<10>), grid, dim3(256), 0, st, feat, ld, cond, B, D, C, Wt, loss_part,
-                               grad_slabs, slab_stride);
+                               grad_slabs, slab_stride, jr);
         else
             hipLaunchKernelGGL((mmd_small_kernel<16>), grid, dim3(256), 0, st, feat, ld, cond, B, D, C, Wt, loss_part,
-                               grad_slabs, slab_stride);
+                               grad_slabs, slab_stride, jr);
     } else {
         const int jt = (B + 15) / 16;
         const int jchunk = ((jt + ns - 1) / ns) * 16;

@@ -35,7 +35,7 @@ class _Layer:
         self.bn = bn        # state-dict prefix of the BatchNorm1d after this Linear (use_bn), e.g. "encoder.FC.N0"
 
 
-_QUERIES = {"sca_gemm_splitk_heuristic", "sca_mmd_num_slabs", "sca_mmd_num_partials", "sca_hsic_workspace_floats",
+_QUERIES = {"sca_mid_max_width", "sca_grad_tail_max_jobs", "sca_gemm_splitk_heuristic", "sca_mmd_num_slabs", "sca_mmd_num_partials", "sca_hsic_workspace_floats",
             "sca_proto_workspace_bytes", "sca_abi_version", "sca_device_name"}
 
 
@@ -246,6 +246,11 @@ class CVAEEngine:
         self._rec = None                # launch-plan recorder (train_step)
         self.overlap = True
         self.set_hyper(alpha_kl=1.0, lr=1e-3, eps=0.01, clip=0.0)
+        # fused middle (fused_mid.hip): trVAE family with LayerNorm / no norm, NB or MSE, narrow hidden layers
+        wmax = self.lib.sca_mid_max_width()
+        self.use_fused_mid = (self.arch == "trvae" and not self.use_bn and self.recon in ("nb", "mse")
+                              and len(self.enc) - 1 <= 4 and 1 <= len(self.dec) <= 4
+                              and max(self.H) <= wmax and 3 * self.Zt <= wmax and bool(s.get("fused_mid", True)))
 
     # ------------------------------------------------------------------------------------------ configuration
     def set_hyper(self, alpha_kl=None, lr=None, eps=None, clip=None, t=None):
@@ -343,6 +348,7 @@ class CVAEEngine:
                 self._hsic_sigmas = [(bw(sd.count(0)), bw(sd.count(1))) for sd in sides]
         ws["da"] = torch.empty(B, max(Hmax, 2 * Z), dtype=f32, device=dev)
         ws["dheads"] = torch.empty(B, 2 * Z, dtype=f32, device=dev)
+        ws["dh0"] = torch.empty(B, H[0], dtype=f32, device=dev)
         # split-K slab workspace: the largest S*M*N over every GEMM of the step
         need = 0
         shapes = []
@@ -368,7 +374,9 @@ class CVAEEngine:
         self._mmd_ns = L.sca_mmd_num_slabs(B, Dm)
         ws["mmd_g"] = torch.empty(max(1, self._mmd_ns) * B * Dm, dtype=f32, device=dev)
         ws["mmd_part"] = torch.zeros(max(1, L.sca_mmd_num_partials(B, Dm)), dtype=torch.float64, device=dev)
-        ws["mmd_g1"] = torch.empty(B, Dm, dtype=f32, device=dev)
+        # one slab (small-D kernel: atomically accumulated) needs no reduction: the consumers read it in place
+        ws["mmd_g1"] = (ws["mmd_g"][:B * Dm].view(B, Dm) if self._mmd_ns == 1
+                        else torch.empty(B, Dm, dtype=f32, device=dev))
         self._sbh = torch.empty(B * Hmax, dtype=f32, device=dev)
         ws["Wt"] = torch.empty(C * C, dtype=f32, device=dev)
         ws["counts"] = torch.empty(C, dtype=torch.int32, device=dev)
@@ -602,10 +610,13 @@ class CVAEEngine:
                                          step_p, st)
 
         # 2. encoder
+        fused = self.use_fused_mid and not (self.use_mmd and self.mmd_on != "z")
         a = ws["x"].data_ptr()
-        for ly in self.enc:
+        for ly in (self.enc[:1] if fused else self.enc):
             a = layer_forward(ly, a)
         self._ev_pro = self._flush()
+        if fused:
+            return self._fused_path(row_ids, cond_p, B, train, compute_grad, eps, masks, accumulate_logs, p_drop, st)
         # 3. heads + sampling + KL
         Hl = self.H[-1]
         # heads: one [2*Zt, H] GEMM, bias fused, no split-K (K = H is short) -> the latent kernel reads one slab
@@ -627,7 +638,7 @@ class CVAEEngine:
                                          -1 if self.boundary is None else int(self.boundary), self.beta,
                                          ws["Wt"].data_ptr(), ws["counts"].data_ptr(), ws["mmd_part"].data_ptr(),
                                          ws["mmd_g"].data_ptr() if compute_grad else None, B * Dm, sa), "mmd")
-            if compute_grad:      # the gradient slabs are summed here, off the critical path
+            if compute_grad and L.sca_mmd_num_slabs(B, Dm) > 1:      # gradient slabs summed off the critical path
                 _lib.check(L.sca_splitk_reduce(ws["mmd_g"].data_ptr(), L.sca_mmd_num_slabs(B, Dm), B * Dm,
                                                ws["mmd_g1"].data_ptr(), B * Dm, sa), "mmd_reduce")
 
@@ -851,6 +862,131 @@ class CVAEEngine:
             self._defer(lambda sa: self._embed_scatter(B, sa))
         self._defer(self._run_tail)
         self._wait(self._flush())
+
+    # ------------------------------------------------------------------------------------------ fused middle
+    def _mid_args(self, B, cond_p, p_drop, eps, masks, dh=None, S=0, stride=0, dz2=None):
+        """sca_mid_args for the current workspace (cached: every pointer is static for a given batch capacity)."""
+        P, ws, ptr = self.p, self.ws, _lib.ptr
+        key = (B, id(ws), cond_p, p_drop, ptr(eps), tuple(sorted((k, v.data_ptr()) for k, v in masks.items())), dh, S,
+               stride, dz2)
+        cache = self.__dict__.setdefault("_mid_cache", {})
+        hit = cache.get(key)
+        if hit is not None:
+            return hit[1]
+        if len(cache) > 32:
+            cache.clear()
+        a = _lib.MidArgs()
+
+        def fill(dst, ly):
+            dst.W, dst.bias = P[ly.w].data_ptr(), ptr(P[ly.b]) if ly.b else None
+            dst.Wc = ptr(P[ly.wc]) if ly.wc else None
+            dst.mask = ptr(masks.get(ly.mask_key))
+            dst.yn, dst.rs = ws[ly.tag + ".yn"].data_ptr(), ws[ly.tag + ".rs"].data_ptr()
+            dst.h, dst.da = ws[ly.tag + ".h"].data_ptr(), ws[ly.tag + ".da"].data_ptr()
+            dst.N, dst.K, dst.rng_stream = ly.n_out, ly.n_in, ly.rng_stream
+        for i, ly in enumerate(self.enc[1:]):
+            fill(a.enc[i], ly)
+        for i, ly in enumerate(self.dec):
+            fill(a.dec[i], ly)
+        a.n_enc, a.n_dec = len(self.enc) - 1, len(self.dec)
+        a.Wh, a.bh, a.eps_in = self.heads_w.data_ptr(), self.heads_b.data_ptr(), ptr(eps)
+        a.mu_lv, a.eps_out = ws["mu_lv"].data_ptr(), ws["eps"].data_ptr()
+        a.z, a.kl_row = ws["z"].data_ptr(), ws["kl_row"].data_ptr()
+        a.Z, a.Kh, a.rng_latent, a.sample = self.Zt, self.H[-1], 1, 1
+        a.B, a.C, a.cond = B, self.C, cond_p
+        a.norm, a.p, a.seed, a.step = self.norm, p_drop, self.seed, self.step_ctr.data_ptr()
+        a.h_in, a.K0, a.S = ws[self.enc[0].tag + ".h"].data_ptr(), self.H[0], S
+        a.dh, a.dh_stride, a.dz2 = dh, stride, dz2
+        a.hyper, a.dheads, a.dh_out = self.hyper.data_ptr(), ws["dheads"].data_ptr(), ws["dh0"].data_ptr()
+        import ctypes
+        cache[key] = (a, ctypes.byref(a))
+        return cache[key][1]
+
+    def _fused_path(self, row_ids, cond_p, B, train, compute_grad, eps, masks, accumulate_logs, p_drop, st):
+        """Step after the first encoder layer with the fused middle kernels: mid_fwd -> (MMD beside) output GEMM ->
+        likelihood -> dX of the output GEMM -> mid_bwd -> first encoder layer backward; weight-side gradients on the
+        aux stream as in the unfused path."""
+        L, P, Gd, ws, T = self.lib, self.p, self.g, self.ws, self.trainable
+        G, C, Z = self.G, self.C, self.Zt
+        ptr = _lib.ptr
+        _lib.check(L.sca_mid_fwd(self._mid_args(B, cond_p, p_drop, eps, masks), st), "mid_fwd")
+        do_mmd = self.use_mmd and C > 0
+        self._n_part = 0
+        if do_mmd:
+            def mmd_work(sa):
+                _lib.check(L.sca_mmd_fwd_bwd(ws["z"].data_ptr(), Z, cond_p, B, Z, C,
+                                             -1 if self.boundary is None else int(self.boundary), self.beta,
+                                             ws["Wt"].data_ptr(), ws["counts"].data_ptr(), ws["mmd_part"].data_ptr(),
+                                             ws["mmd_g"].data_ptr() if compute_grad else None, B * Z, sa), "mmd")
+                if compute_grad and L.sca_mmd_num_slabs(B, Z) > 1:
+                    _lib.check(L.sca_splitk_reduce(ws["mmd_g"].data_ptr(), L.sca_mmd_num_slabs(B, Z), B * Z,
+                                                   ws["mmd_g1"].data_ptr(), B * Z, sa), "mmd_reduce")
+            self._n_part = L.sca_mmd_num_partials(B, Z)
+            self._defer(mmd_work)
+        ev_side = self._flush()
+        Hd = self.dec[-1].n_out
+        h_last = ws[self.dec[-1].tag + ".h"].data_ptr()
+        self._gemm(0, 0, h_last, Hd, P[self.out_w].data_ptr(), Hd, B, G, Hd, st, out=ws["logits"].data_ptr(), ldc=G,
+                   bias=P[self.out_b].data_ptr(), force_s1=True)
+        self._wait(self._ev_pro)
+        rpb = max(1, B // 1024)
+        gob = self.g[self.out_b].data_ptr() if T[self.out_b] else None
+        if self.recon == "mse":
+            _lib.check(L.sca_mse_rows(ws["logits"].data_ptr(), G, ws["x"].data_ptr(), G, B, G, rpb,
+                                      ws["row_ll"].data_ptr(), gob, int(compute_grad), 1, None, None, st), "mse_rows")
+            recon_sign = 1.0
+        else:
+            ip, ix, dv = self.csr
+            _lib.check(L.sca_recon_rows(0, ws["logits"].data_ptr(), G, None, ip.data_ptr(), ix.data_ptr(),
+                                        dv.data_ptr(), ptr(row_ids), ws["sf"].data_ptr(), cond_p,
+                                        ws["tab_theta"].data_ptr(), ws["tab_lte"].data_ptr(), B, G, max(C, 1), rpb,
+                                        ws["row_ll"].data_ptr(), ws["dthetaT"].data_ptr(), gob, None,
+                                        int(compute_grad), None, st), "recon_rows")
+            recon_sign = -1.0
+        self._defer_finalize(recon_sign, B, accumulate_logs)
+        if not compute_grad:
+            self._wait(self._flush())
+            return self.losses
+        # ---- backward
+        dl = ws["logits"].data_ptr()
+
+        def recon_side(sa):
+            if self.recon != "mse" and T["theta"]:
+                _lib.check(L.sca_transpose_scale(ws["dthetaT"].data_ptr(), max(C, 1), G, -1.0 / B,
+                                                 Gd["theta"].data_ptr(), sa), "transpose_scale")
+            if T[self.out_w]:
+                self._grad_gemm(1, 1, dl, G, h_last, Hd, G, Hd, B, sa, Gd[self.out_w])
+        self._defer(recon_side)
+        sp, S, stride = self._gemm(0, 1, dl, G, P[self.out_w].data_ptr(), Hd, B, Hd, G, st)
+        if do_mmd:
+            self._wait(ev_side)
+        _lib.check(L.sca_mid_bwd(self._mid_args(B, cond_p, p_drop, eps, masks, sp, S, stride,
+                                                ws["mmd_g1"].data_ptr() if do_mmd else None), st), "mid_bwd")
+        # weight-side gradients of every middle layer: one dependency point, aux stream
+        mids = [(ly, ws["z"].data_ptr() if i == 0 else ws[self.dec[i - 1].tag + ".h"].data_ptr())
+                for i, ly in enumerate(self.dec)]
+        mids += [(ly, ws[self.enc[i].tag + ".h"].data_ptr()) for i, ly in enumerate(self.enc[1:])]
+        Hl = self.H[-1]
+        h_enc, dh = ws[self.enc[-1].tag + ".h"].data_ptr(), ws["dheads"].data_ptr()
+
+        def mid_side(sa):
+            for ly, a_prev in mids:
+                da = ws[ly.tag + ".da"].data_ptr()
+                if T[ly.w]:
+                    self._grad_gemm(1, 1, da, ly.n_out, a_prev, ly.n_in, ly.n_out, ly.n_in, B, sa, Gd[ly.w])
+                need_b, need_c = bool(ly.b) and T[ly.b], bool(ly.wc) and T[ly.wc]
+                if need_b or need_c:
+                    self._colsum(da, B, ly.n_out, cond_p, C, Gd[ly.wc].data_ptr() if need_c else None,
+                                 Gd[ly.b].data_ptr() if need_b else None, sa)
+            if any(T[k] for k in self.heads_names):
+                self._grad_gemm(1, 1, dh, 2 * Z, h_enc, Hl, 2 * Z, Hl, B, sa, self.heads_gw)
+                self._colsum(dh, B, 2 * Z, None, 0, None, self.heads_gb.data_ptr(), sa)
+        self._defer(mid_side)
+        self._layer_backward(self.enc[0], ws["x"].data_ptr(), ws["dh0"].data_ptr(), 1, 0, None, False, B, cond_p,
+                             p_drop, masks, st)
+        self._defer(self._run_tail)
+        self._wait(self._flush())
+        return self.losses
 
     # ------------------------------------------------------------------------------------------ scPoli
     def _embed_lookup(self, covs, B, st):

@@ -1,0 +1,50 @@
+"""Dev probe: time the fused middle kernels alone (HIP events), dropout on/off, a few batch sizes."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bench import build_trvae_params, epoch_batches
+from scarches_amd import _lib
+from scarches_amd.engine import CVAEEngine
+from scarches_amd.synth import make_synthetic_csr
+
+dev = torch.device("cuda", 0)
+G, C, Z, H = 2000, 20, 10, [128, 128]
+indptr, indices, data, cond_all, _ = make_synthetic_csr(50_000, G, C, dev, seed=1000)
+P = build_trvae_params(G, C, H, Z)
+gen = torch.Generator(device=dev); gen.manual_seed(1)
+for B in (128, 4096, 16384):
+    for p in (0.0, 0.05):
+        spec = dict(G=G, C=C, H=H, Z=Z, recon="nb", use_bn=False, use_ln=True, use_mmd=True, mmd_on="z",
+                    boundary=None, beta=1.0, dr_rate=p, seed=2020)
+        eng = CVAEEngine(spec, P, dev)
+        eng.bind_csr(indptr, indices, data)
+        ids, cs = epoch_batches(cond_all, 2, B, gen)
+        eng.begin_step(0.5, 1e-3)
+        eng.forward_backward(ids[0], cs[0], B)
+        torch.cuda.synchronize()
+        st = torch.cuda.current_stream().cuda_stream
+        L = _lib.load()
+        (af, rf), = [v for k, v in eng._mid_cache.items() if k[6] is None]
+        (ab, rb), = [v for k, v in eng._mid_cache.items() if k[6] is not None]
+        for name, fn, ref in (("fwd", L.sca_mid_fwd, rf), ("bwd", L.sca_mid_bwd, rb)):
+            for _ in range(3):
+                fn(ref, st)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                fn(ref, st)
+            e1.record()
+            torch.cuda.synchronize()
+            print(f"B={B:6d} p={p:.2f} mid_{name}: {e0.elapsed_time(e1) / 20 * 1e3:8.1f} us", flush=True)
+
+# debug build only: phase timestamps of workgroup 0 (100 MHz wall clock)
+import ctypes
+try:
+    fn = L.sca_mid_debug
+    buf = (ctypes.c_longlong * 64)()
+    L.sca_mid_fwd(rf, st); torch.cuda.synchronize()
+    fn(buf)
+    t = [buf[i] for i in range(10)]
+    print("fwd phases (us since start):", [round((x - t[0]) / 100.0, 2) for x in t])
+except AttributeError:
+    pass

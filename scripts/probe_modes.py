@@ -11,7 +11,7 @@ G, C, Z, H = 2000, 20, 10, [128, 128]
 indptr, indices, data, cond_all, _ = make_synthetic_csr(200_000, G, C, dev, seed=1000)
 P = build_trvae_params(G, C, H, Z)
 spec = dict(G=G, C=C, H=H, Z=Z, recon="nb", use_bn=False, use_ln=True, use_mmd=True, mmd_on="z", boundary=None,
-            beta=1.0, dr_rate=0.05, seed=2020)
+            beta=1.0, dr_rate=0.05, seed=2020, fused_mid=os.environ.get("SCA_FUSED", "1") == "1")
 gen = torch.Generator(device=dev); gen.manual_seed(1)
 batches = [int(b) for b in (sys.argv[1].split(",") if len(sys.argv) > 1 else "128,1024,4096,16384".split(","))]
 for B in batches:
