@@ -119,6 +119,12 @@ int sca_adam_step(float* p, const float* g, float* m, float* v, long long n, con
  * sca_fill_zero: zero `bytes` bytes (optimizer.zero_grad() for the accumulating gradient targets). */
 int sca_begin_step(float* hyper, uint32_t* step_ctr, float alpha_kl, float lr, float bias_corr1,
                    float bias_corr2_sqrt, float eps, float clip, void* stream);
+/* sca_begin_step plus the copy of the step's row ids [B] (int64) and conditions [B] (int32) into the static
+ * buffers that a recorded launch plan / HIP graph reads: the reference hands each minibatch to the model as fresh
+ * tensors (trainers/trvae/trainer.py:305-312 on_iteration), a replayed plan needs them at fixed addresses. */
+int sca_begin_step_batch(float* hyper, uint32_t* step_ctr, float alpha_kl, float lr, float bias_corr1,
+                         float bias_corr2_sqrt, float eps, float clip, const int64_t* rows_src, int64_t* rows_dst,
+                         const int32_t* cond_src, int32_t* cond_dst, int B, void* stream);
 int sca_fill_zero(void* p, long long bytes, void* stream);
 int sca_finalize_losses(const float* row_recon, float recon_sign, const float* row_kl, int B, const double* mmd_part,
                         int n_part, const float* hyper, float* losses, double* accum, void* stream);
@@ -166,6 +172,11 @@ typedef struct {
     int32_t norm; float p; uint64_t seed; const uint32_t* step;
     const float* h_in; int32_t K0, S;
     const float* dh; long long dh_stride; const float* dz2; const float* hyper; float* dheads; float* dh_out;
+    /* optional: the first encoder layer's epilogue fused in (its GEMM stays a separate launch) */
+    int32_t fuse_first, S0;
+    const float* pre0;     /* [S0][B][K0] split-K slabs of x W0^T (forward) */
+    long long pre0_stride;
+    sca_mid_layer first;   /* bias / Wc / mask / yn / rs / h / da of the first layer (W, K unused); N == K0 */
 } sca_mid_args;
 int sca_mid_max_width(void);
 int sca_mid_fwd(const sca_mid_args* a, void* stream);

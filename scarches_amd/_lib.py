@@ -43,7 +43,9 @@ class MidArgs(C.Structure):
                 ("norm", C.c_int32), ("p", C.c_float), ("seed", C.c_uint64), ("step", C.c_void_p),
                 ("h_in", C.c_void_p), ("K0", C.c_int32), ("S", C.c_int32),
                 ("dh", C.c_void_p), ("dh_stride", C.c_longlong), ("dz2", C.c_void_p), ("hyper", C.c_void_p),
-                ("dheads", C.c_void_p), ("dh_out", C.c_void_p)]
+                ("dheads", C.c_void_p), ("dh_out", C.c_void_p),
+                ("fuse_first", C.c_int32), ("S0", C.c_int32), ("pre0", C.c_void_p), ("pre0_stride", C.c_longlong),
+                ("first", MidLayer)]
 
 
 # name -> argtypes (restype is always int); mirrors include/scarches_hip.h one to one
@@ -71,6 +73,7 @@ SIGNATURES = {
     "sca_adam_step": [P, P, P, P, LL, P, F, F, F, P],
     "sca_finalize_losses": [P, F, P, I, P, I, P, P, P, P],
     "sca_begin_step": [P, P, F, F, F, F, F, F, P],
+    "sca_begin_step_batch": [P, P, F, F, F, F, F, F, P, P, P, P, I, P],
     "sca_fill_zero": [P, LL, P],
     "sca_masked_copy": [P, I, P, I, P, I, I, I, P],
     "sca_prox_l1": [P, LL, F, P, P],

@@ -69,7 +69,39 @@ __global__ void begin_step_kernel(float* __restrict__ hyper, uint32_t* __restric
     }
 }
 
+// begin_step + staging of the minibatch ids / conditions into the static buffers a recorded launch plan or HIP graph
+// reads (one launch instead of a kernel and two copies at the head of every step).
+__global__ __launch_bounds__(256) void begin_step_batch_kernel(float* __restrict__ hyper,
+                                                               uint32_t* __restrict__ step_ctr, float a, float lr,
+                                                               float bc1, float bc2s, float eps, float clip,
+                                                               const int64_t* __restrict__ rows_src,
+                                                               int64_t* __restrict__ rows_dst,
+                                                               const int32_t* __restrict__ cond_src,
+                                                               int32_t* __restrict__ cond_dst, int B) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) {
+        hyper[0] = a; hyper[1] = lr; hyper[2] = bc1; hyper[3] = bc2s; hyper[4] = eps; hyper[5] = clip;
+        if (step_ctr) step_ctr[0] += 1u;
+    }
+    if (i < B) {
+        if (rows_dst) rows_dst[i] = rows_src[i];
+        if (cond_dst) cond_dst[i] = cond_src[i];
+    }
+}
+
 }  // namespace
+
+extern "C" int sca_begin_step_batch(float* hyper, uint32_t* step_ctr, float alpha_kl, float lr, float bias_corr1,
+                                    float bias_corr2_sqrt, float eps, float clip, const int64_t* rows_src,
+                                    int64_t* rows_dst, const int32_t* cond_src, int32_t* cond_dst, int B,
+                                    void* stream) {
+    if (B < 0 || (rows_dst && !rows_src) || (cond_dst && !cond_src)) return -1;
+    const int nb = B > 0 ? (B + 255) / 256 : 1;
+    hipLaunchKernelGGL(begin_step_batch_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, hyper, step_ctr, alpha_kl,
+                       lr, bias_corr1, bias_corr2_sqrt, eps, clip, rows_src, rows_dst, cond_src, cond_dst, B);
+    SCA_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int sca_begin_step(float* hyper, uint32_t* step_ctr, float alpha_kl, float lr, float bias_corr1,
                               float bias_corr2_sqrt, float eps, float clip, void* stream) {

@@ -57,6 +57,11 @@ typedef struct {
     const float* hyper;    // hyper[0] = alpha_kl
     float* dheads;         // [B][2Z]
     float* dh_out;         // [B][K0] gradient w.r.t. h_in
+    // optional: the first encoder layer's epilogue fused in (its GEMM stays a separate launch)
+    int32_t fuse_first, S0;
+    const float* pre0;     // [S0][B][K0] split-K slabs of x W0^T (forward)
+    long long pre0_stride;
+    sca_mid_layer first;   // bias / Wc / mask / yn / rs / h / da of the first layer (W, K unused); N == K0
 } sca_mid_args;
 }
 
@@ -303,10 +308,17 @@ __global__ __launch_bounds__(256) void mid_fwd_kernel(const sca_mid_args a, int 
     float* A1 = A0 + TM * ld;          // [TM][ld]
     float* Ms = A1 + TM * ld;          // [KC][MS_LD]
     const int r0 = blockIdx.x * TM;
-    // input tile (zero padded to a multiple of KC columns)
-    load_tile(A0, ld, a.h_in, 1, 0, r0, a.B, a.K0, ((a.K0 + KC - 1) / KC) * KC);
     float* cur = A0;
     float* oth = A1;
+    if (a.fuse_first) {
+        // first encoder layer: sum of the GEMM's split-K slabs -> bias / condition column / LayerNorm / ReLU / dropout
+        load_tile(oth, ld, a.pre0, a.S0, a.pre0_stride, r0, a.B, a.K0, a.K0);
+        __syncthreads();
+        layer_epilogue_fwd<2 * NS>(a, a.first, oth, cur, ld, r0);
+    } else {
+        // input tile (zero padded to a multiple of KC columns)
+        load_tile(A0, ld, a.h_in, 1, 0, r0, a.B, a.K0, ((a.K0 + KC - 1) / KC) * KC);
+    }
     DBG(0);
     for (int l = 0; l < a.n_enc; ++l) {
         const sca_mid_layer& L = a.enc[l];
@@ -508,6 +520,10 @@ __global__ __launch_bounds__(256) void mid_bwd_kernel(const sca_mid_args a, int 
         layer_epilogue_bwd<2 * NS>(a, L, cur, oth, ld, r0);
         tile_gemm<false>(oth, ld, L.N, L.W, L.K, L.K, cur, ld, Ms);
     }
+    if (a.fuse_first) {                  // first encoder layer backward: `cur` = d h0 -> da0 (its dW GEMM reads it)
+        layer_epilogue_bwd<2 * NS>(a, a.first, cur, oth, ld, r0);
+        return;
+    }
     if ((a.K0 & 3) == 0 && ((uintptr_t)a.dh_out & 15) == 0) {
         const int w4 = a.K0 >> 2;
         for (int t = threadIdx.x; t < TM * w4; t += 256) {
@@ -535,6 +551,10 @@ int check_and_ld(const sca_mid_args* a, int* ld, size_t* shm, int* wide) {
     int maxn = 0;
     for (int l = 0; l < a->n_enc; ++l) if (a->enc[l].N > maxn) maxn = a->enc[l].N;
     for (int l = 0; l < a->n_dec; ++l) if (a->dec[l].N > maxn) maxn = a->dec[l].N;
+    if (a->fuse_first) {
+        if (a->first.N != a->K0 || a->S0 < 1 || !a->pre0) return -1;
+        if (a->K0 > maxn) maxn = a->K0;
+    }
     *wide = maxn > 128;
     *ld = ((maxw + KC - 1) / KC) * KC + 1;
     *shm = sizeof(float) * ((size_t)2 * TM * (*ld) + (size_t)KC * MS_LD);
@@ -571,7 +591,7 @@ extern "C" int sca_mid_bwd(const sca_mid_args* a, void* stream) {
     int ld, wide; size_t shm;
     const int rc = check_and_ld(a, &ld, &shm, &wide);
     if (rc) return rc > 0 ? 0 : rc;
-    if (!a->dh || !a->dheads || !a->dh_out || !a->hyper) return -1;
+    if (!a->dh || !a->dheads || !a->hyper || (!a->fuse_first && !a->dh_out)) return -1;
     const dim3 grid((a->B + TM - 1) / TM);
     if (wide) {
         hipFuncSetAttribute((const void*)mid_bwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);

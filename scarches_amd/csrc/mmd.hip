@@ -120,56 +120,78 @@ __global__ __launch_bounds__(256) void mmd_prepare_kernel(const int32_t* __restr
 //     lane with d2 > 1.75 - one ballot skips the five exps (taken for all but near-coincident pairs);
 //   * alpha >= 100: the five widest kernels are one degree-7 polynomial pair while every lane has d2 <= 64.
 // The nine bandwidths in between take one v_mul + one raw v_exp_f32 (2^x) + two accumulates each.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
+
+// KK[u] = (K, Kp) of pair u.  Written for the packed fp32 VALU ops of gfx950 (two lanes of work per instruction):
+// the exp arguments of two pairs share one v_pk_mul_f32, each exp feeds (K, Kp) with one v_pk_fma_f32, and the two
+// Horner chains of the wide-bandwidth polynomial run as one packed chain.
 template <int U>
-__device__ __forceinline__ void rbf_terms(int a, const float (&d2)[U], float (&K)[U], float (&Kp)[U]) {
+__device__ __forceinline__ void rbf_terms(int a, const float (&d2)[U], v2f (&KK)[U]) {
     constexpr float LOG2E = 1.4426950408889634f;
     const float beta = MMD_BETA[a];
+    const float c = -(beta * LOG2E);
+    const v2f ob = {1.0f, beta};
+    if constexpr (U % 2 == 0) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const float e = __builtin_amdgcn_exp2f(-(beta * LOG2E) * d2[u]);
-        K[u] += e;
-        Kp[u] = fmaf(beta, e, Kp[u]);
+        for (int u = 0; u < U; u += 2) {
+            const v2f arg = v2f{d2[u], d2[u + 1]} * v2f{c, c};
+            const float e0 = __builtin_amdgcn_exp2f(arg.x), e1 = __builtin_amdgcn_exp2f(arg.y);
+            KK[u] = pk_fma(v2f{e0, e0}, ob, KK[u]);
+            KK[u + 1] = pk_fma(v2f{e1, e1}, ob, KK[u + 1]);
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const float e = __builtin_amdgcn_exp2f(c * d2[u]);
+            KK[u] = pk_fma(v2f{e, e}, ob, KK[u]);
+        }
     }
 }
 // U independent pairs per call: the per-pair chains (exp -> accumulate, Horner) are latency-bound on their own
 template <int U>
-__device__ __forceinline__ void rbf19(const float (&d2)[U], float (&K)[U], float (&Kp)[U]) {
+__device__ __forceinline__ void rbf19(const float (&d2)[U], v2f (&KK)[U]) {
     bool near = false, far = false;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        K[u] = 0.f; Kp[u] = 0.f;
+        KK[u] = v2f{0.f, 0.f};
         near |= d2[u] < 1.75f;
         far |= d2[u] > MMD_POLY_MAX_D2;
     }
 #pragma unroll
-    for (int a = 5; a < MMD_WIDE0; ++a) rbf_terms<U>(a, d2, K, Kp);
+    for (int a = 5; a < MMD_WIDE0; ++a) rbf_terms<U>(a, d2, KK);
+    // (the opaque copies pin the rarely needed exps inside their branches: hipcc otherwise speculates them)
     if (__ballot(near) != 0ull) {
+        float dn[U];
 #pragma unroll
-        for (int a = 0; a < 5; ++a) rbf_terms<U>(a, d2, K, Kp);
+        for (int u = 0; u < U; ++u) { dn[u] = d2[u]; asm volatile("" : "+v"(dn[u])); }
+#pragma unroll
+        for (int a = 0; a < 5; ++a) rbf_terms<U>(a, dn, KK);
     }
     if (__ballot(far) == 0ull) {
-        float k[U], p[U];
+        v2f kp[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { k[u] = MmdPoly<7>::cK; p[u] = MmdPoly<7>::cP; }
-#define MMD_HORNER(N)                                                                   \
-        _Pragma("unroll") for (int u = 0; u < U; ++u) {                                 \
-            k[u] = fmaf(k[u], d2[u], MmdPoly<N>::cK);                                   \
-            p[u] = fmaf(p[u], d2[u], MmdPoly<N>::cP);                                   \
-        }
+        for (int u = 0; u < U; ++u) kp[u] = v2f{MmdPoly<7>::cK, MmdPoly<7>::cP};
+#define MMD_HORNER(N)                                                                               \
+        _Pragma("unroll") for (int u = 0; u < U; ++u)                                               \
+            kp[u] = pk_fma(kp[u], v2f{d2[u], d2[u]}, v2f{MmdPoly<N>::cK, MmdPoly<N>::cP});
         MMD_HORNER(6) MMD_HORNER(5) MMD_HORNER(4) MMD_HORNER(3) MMD_HORNER(2) MMD_HORNER(1) MMD_HORNER(0)
 #undef MMD_HORNER
 #pragma unroll
-        for (int u = 0; u < U; ++u) { K[u] += k[u]; Kp[u] += p[u]; }
+        for (int u = 0; u < U; ++u) KK[u] += kp[u];
     } else {
+        float dw[U];
 #pragma unroll
-        for (int a = MMD_WIDE0; a < 19; ++a) rbf_terms<U>(a, d2, K, Kp);
+        for (int u = 0; u < U; ++u) { dw[u] = d2[u]; asm volatile("" : "+v"(dw[u])); }
+#pragma unroll
+        for (int a = MMD_WIDE0; a < 19; ++a) rbf_terms<U>(a, dw, KK);
     }
 }
 __device__ __forceinline__ void rbf19(float d2, float& K, float& Kp) {
     const float d[1] = {d2};
-    float k[1], p[1];
-    rbf19<1>(d, k, p);
-    K = k[0]; Kp = p[0];
+    v2f kk[1];
+    rbf19<1>(d, kk);
+    K = kk[0].x; Kp = kk[0].y;
 }
 
 constexpr int MMD_T = 64;     // rows per wave (== wave size)
@@ -190,9 +212,9 @@ __global__ __launch_bounds__(256) void mmd_small_kernel(const float* __restrict_
                                                         const float* __restrict__ Wt, double* __restrict__ loss_part,
                                                         float* __restrict__ grad, long long slab_stride, int JR) {
     constexpr int KH = (DMAX + 1) / 2;        // features per half-wave in the transposed pass
-    static_assert(KH <= 8, "transposed pass reads two float4 per row");
-    __shared__ __attribute__((aligned(16))) float zis[4][MMD_T * 16];   // [i][half*8 + q] = z_i[half*KH + q]
-    __shared__ float zj[MMD_TC * DMAX];
+    constexpr int ZS = ((KH + 1 + 3) / 4) * 4;                          // floats per (row, half) in the staged rows
+    __shared__ __attribute__((aligned(16))) float zis[4][MMD_T * 2 * ZS];
+    __shared__ __attribute__((aligned(8))) float zj[MMD_TC * DMAX];
     __shared__ int cj[MMD_TC];
     __shared__ float Pt[4][MMD_TC * MMD_PLD];  // per wave: coef tile [column][row]; later the wave's column gradients
     __shared__ double redd[16];
@@ -216,30 +238,37 @@ __global__ __launch_bounds__(256) void mmd_small_kernel(const float* __restrict_
     const int ci = act ? cond[i] : -1;
     const bool ok = ci >= 0 && ci < C;
     const float* wrow = Wt + (long long)(ok ? ci : 0) * C;
-    float zi[DMAX], gr[DMAX];
+    static_assert(DMAX % 2 == 0, "features are processed as packed pairs");
+    constexpr int DP = DMAX / 2;
+    float zi[DMAX];
+    v2f zi2[DP], gr2[DP];
 #pragma unroll
-    for (int k = 0; k < DMAX; ++k) {
-        zi[k] = (act && k < D) ? z[(long long)i * ldz + k] : 0.f;
-        gr[k] = 0.f;
+    for (int k = 0; k < DMAX; ++k) zi[k] = (act && k < D) ? z[(long long)i * ldz + k] : 0.f;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+        zi2[k] = v2f{zi[2 * k], zi[2 * k + 1]};
+        gr2[k] = v2f{0.f, 0.f};
     }
+    // staged rows for the transposed pass: [i][half][ZS] = {1, z_i[half*KH .. half*KH + KH)} (the leading 1 makes
+    // sum_i coef part of the same packed FMA chain)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float v = 0.f;
+        for (int q = 0; q < ZS; ++q) {
+            float v = q == 0 ? 1.0f : 0.f;
 #pragma unroll
             for (int k = 0; k < DMAX; ++k)
-                if (q < KH && k == h * KH + q) v = zi[k];
-            zis[w][lane * 16 + h * 8 + q] = v;
+                if (q >= 1 && q <= KH && k == h * KH + q - 1) v = zi[k];
+            zis[w][lane * (2 * ZS) + h * ZS + q] = v;
         }
     float lsum = 0.f;
     const int jp = lane & (MMD_TC - 1), kh = lane >> 5;       // transposed pass: column of the chunk, feature half
     for (int J = Jbeg; J < Jend; ++J) {
         const int j0 = J * MMD_TC, nj = min(B - j0, MMD_TC);
         __syncthreads();                       // previous chunk fully consumed
-        for (int t = threadIdx.x; t < nj * D; t += 256) {
-            const int jj = t / D, k = t - jj * D;
-            zj[jj * DMAX + k] = z[(long long)(j0 + jj) * ldz + k];
+        for (int t = threadIdx.x; t < nj * DMAX; t += 256) {      // features past D are stored as zeros
+            const int jj = t / DMAX, k = t - jj * DMAX;
+            zj[jj * DMAX + k] = k < D ? z[(long long)(j0 + jj) * ldz + k] : 0.f;
         }
         if (threadIdx.x < MMD_TC) cj[threadIdx.x] = threadIdx.x < nj ? cond[j0 + threadIdx.x] : -1;
         __syncthreads();
@@ -258,24 +287,27 @@ __global__ __launch_bounds__(256) void mmd_small_kernel(const float* __restrict_
             // U columns of one condition run: U independent diff -> d2 -> exp -> accumulate chains
             auto columns = [&](auto UU, int jj) {
                 constexpr int U = decltype(UU)::value;
-                float diff[U][DMAX], d2[U], K[U], Kp[U];
+                v2f diff[U][DP], KK[U];
+                float d2[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    d2[u] = 0.f;
+                    const v2f* zc = reinterpret_cast<const v2f*>(&zj[(jj + u) * DMAX]);
+                    v2f acc = {0.f, 0.f};
 #pragma unroll
-                    for (int k = 0; k < DMAX; ++k) {
-                        diff[u][k] = zi[k] - zj[(jj + u) * DMAX + k];   // k >= D: LDS pad never reaches the result
-                        if (k < D) d2[u] = fmaf(diff[u][k], diff[u][k], d2[u]);
+                    for (int k = 0; k < DP; ++k) {
+                        diff[u][k] = zi2[k] - zc[k];
+                        acc = pk_fma(diff[u][k], diff[u][k], acc);
                     }
+                    d2[u] = acc.x + acc.y;
                 }
-                rbf19<U>(d2, K, Kp);
+                rbf19<U>(d2, KK);
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    lsum = fmaf(wl, K[u], lsum);
-                    const float coef = w4 * Kp[u];
+                    lsum = fmaf(wl, KK[u].x, lsum);
+                    const float coef = w4 * KK[u].y;
+                    const v2f cc = {coef, coef};
 #pragma unroll
-                    for (int k = 0; k < DMAX; ++k)
-                        if (k < D) gr[k] = fmaf(coef, diff[u][k], gr[k]);
+                    for (int k = 0; k < DP; ++k) gr2[k] = pk_fma(cc, diff[u][k], gr2[k]);
                     if (park) Pt[w][(jj + u) * MMD_PLD + lane] = coef;
                 }
             };
@@ -293,25 +325,28 @@ __global__ __launch_bounds__(256) void mmd_small_kernel(const float* __restrict_
             }
             if (park) {
                 // roles swapped: lane = (column jp, feature half kh); rows of this wave come from LDS
-                float csum = 0.f, acc[KH];
+                v2f acc2[ZS / 2];                  // (sum coef, acc_0), (acc_1, acc_2), ...
 #pragma unroll
-                for (int q = 0; q < KH; ++q) acc[q] = 0.f;
+                for (int q = 0; q < ZS / 2; ++q) acc2[q] = v2f{0.f, 0.f};
                 const float* prow = &Pt[w][jp * MMD_PLD];
-                const float* zr = &zis[w][kh * 8];
+                const float* zr = &zis[w][kh * ZS];
 #pragma unroll 8
                 for (int i2 = 0; i2 < MMD_T; ++i2) {
                     const float c = prow[i2];
-                    const float4 a0 = *reinterpret_cast<const float4*>(zr + i2 * 16);
-                    const float4 a1 = *reinterpret_cast<const float4*>(zr + i2 * 16 + 4);
-                    const float zv[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                    csum += c;
+                    const v2f cc = {c, c};
 #pragma unroll
-                    for (int q = 0; q < KH; ++q) acc[q] = fmaf(c, zv[q], acc[q]);
+                    for (int q4 = 0; q4 < ZS / 4; ++q4) {
+                        const float4 a = *reinterpret_cast<const float4*>(zr + i2 * (2 * ZS) + 4 * q4);
+                        acc2[2 * q4] = pk_fma(cc, v2f{a.x, a.y}, acc2[2 * q4]);
+                        acc2[2 * q4 + 1] = pk_fma(cc, v2f{a.z, a.w}, acc2[2 * q4 + 1]);
+                    }
                 }
+                const float csum = acc2[0].x;
 #pragma unroll
                 for (int q = 0; q < KH; ++q) {
                     const int k = kh * KH + q;
-                    gj[q] = (jp < nj && k < D) ? fmaf(zj[jp * DMAX + k], csum, -acc[q]) : 0.f;
+                    const float aq = ((q + 1) & 1) ? acc2[(q + 1) / 2].y : acc2[(q + 1) / 2].x;
+                    gj[q] = (jp < nj && k < D) ? fmaf(zj[jp * DMAX + k], csum, -aq) : 0.f;
                 }
             }
         }
@@ -335,7 +370,7 @@ __global__ __launch_bounds__(256) void mmd_small_kernel(const float* __restrict_
     if (act && gslab) {
 #pragma unroll
         for (int k = 0; k < DMAX; ++k)
-            if (k < D) gslab[k] = gr[k];
+            if (k < D) gslab[k] = (k & 1) ? gr2[k / 2].y : gr2[k / 2].x;
     }
 }
 

@@ -612,11 +612,15 @@ class CVAEEngine:
         # 2. encoder
         fused = self.use_fused_mid and not (self.use_mmd and self.mmd_on != "z")
         a = ws["x"].data_ptr()
-        for ly in (self.enc[:1] if fused else self.enc):
+        if fused:       # first layer: GEMM only, its epilogue runs inside mid_fwd
+            ly = self.enc[0]
+            pre0 = self._gemm(0, 0, a, ly.n_in, P[ly.w].data_ptr(), ly.n_in, B, ly.n_out, ly.n_in, st)
+            self._ev_pro = self._flush()
+            return self._fused_path(row_ids, cond_p, B, train, compute_grad, eps, masks, accumulate_logs, p_drop, st,
+                                    pre0)
+        for ly in self.enc:
             a = layer_forward(ly, a)
         self._ev_pro = self._flush()
-        if fused:
-            return self._fused_path(row_ids, cond_p, B, train, compute_grad, eps, masks, accumulate_logs, p_drop, st)
         # 3. heads + sampling + KL
         Hl = self.H[-1]
         # heads: one [2*Zt, H] GEMM, bias fused, no split-K (K = H is short) -> the latent kernel reads one slab
@@ -785,7 +789,8 @@ class CVAEEngine:
             self._wait(ev_side)         # MMD / prototype gradient w.r.t. z (finished long ago on the aux stream)
         self._backward_latent_encoder(B, cond_p, p_drop, masks, st, sp, S, stride, dz2, S2)
 
-    def _layer_backward(self, ly, a_prev, sp, S, stride, extra, need_dx, B, cond_p, p_drop, masks, st):
+    def _layer_backward(self, ly, a_prev, sp, S, stride, extra, need_dx, B, cond_p, p_drop, masks, st,
+                        have_da=False):
         """Gradient through one Linear(+cond) -> norm -> ReLU -> dropout block: `da` and (need_dx) the dX GEMM slabs for
         the layer below on the main stream; the weight / bias / condition-weight gradients are deferred to the aux
         stream."""
@@ -795,7 +800,9 @@ class CVAEEngine:
         AUX = "slab_aux" if self.overlap else "slab"
         m = masks.get(ly.mask_key)
         da = ws[ly.tag + ".da"].data_ptr()
-        if ly.bn is None:
+        if have_da:
+            pass
+        elif ly.bn is None:
             _lib.check(L.sca_layer_bwd(sp, S, stride, extra, B, ly.n_out, ws[ly.tag + ".yn"].data_ptr(),
                                        ws[ly.tag + ".rs"].data_ptr(), self.norm, 1, p_drop, ptr(m), self.seed,
                                        ly.rng_stream, self.step_ctr.data_ptr(), da, st), "layer_bwd")
@@ -864,11 +871,11 @@ class CVAEEngine:
         self._wait(self._flush())
 
     # ------------------------------------------------------------------------------------------ fused middle
-    def _mid_args(self, B, cond_p, p_drop, eps, masks, dh=None, S=0, stride=0, dz2=None):
+    def _mid_args(self, B, cond_p, p_drop, eps, masks, dh=None, S=0, stride=0, dz2=None, pre0=None):
         """sca_mid_args for the current workspace (cached: every pointer is static for a given batch capacity)."""
         P, ws, ptr = self.p, self.ws, _lib.ptr
         key = (B, id(ws), cond_p, p_drop, ptr(eps), tuple(sorted((k, v.data_ptr()) for k, v in masks.items())), dh, S,
-               stride, dz2)
+               stride, dz2, pre0)
         cache = self.__dict__.setdefault("_mid_cache", {})
         hit = cache.get(key)
         if hit is not None:
@@ -898,18 +905,21 @@ class CVAEEngine:
         a.h_in, a.K0, a.S = ws[self.enc[0].tag + ".h"].data_ptr(), self.H[0], S
         a.dh, a.dh_stride, a.dz2 = dh, stride, dz2
         a.hyper, a.dheads, a.dh_out = self.hyper.data_ptr(), ws["dheads"].data_ptr(), ws["dh0"].data_ptr()
+        if pre0 is not None:      # first encoder layer's epilogue inside the fused kernels
+            a.fuse_first, (a.pre0, a.S0, a.pre0_stride) = 1, pre0
+            fill(a.first, self.enc[0])
         import ctypes
         cache[key] = (a, ctypes.byref(a))
         return cache[key][1]
 
-    def _fused_path(self, row_ids, cond_p, B, train, compute_grad, eps, masks, accumulate_logs, p_drop, st):
+    def _fused_path(self, row_ids, cond_p, B, train, compute_grad, eps, masks, accumulate_logs, p_drop, st, pre0):
         """Step after the first encoder layer with the fused middle kernels: mid_fwd -> (MMD beside) output GEMM ->
         likelihood -> dX of the output GEMM -> mid_bwd -> first encoder layer backward; weight-side gradients on the
         aux stream as in the unfused path."""
         L, P, Gd, ws, T = self.lib, self.p, self.g, self.ws, self.trainable
         G, C, Z = self.G, self.C, self.Zt
         ptr = _lib.ptr
-        _lib.check(L.sca_mid_fwd(self._mid_args(B, cond_p, p_drop, eps, masks), st), "mid_fwd")
+        _lib.check(L.sca_mid_fwd(self._mid_args(B, cond_p, p_drop, eps, masks, pre0=pre0), st), "mid_fwd")
         do_mmd = self.use_mmd and C > 0
         self._n_part = 0
         if do_mmd:
@@ -961,7 +971,8 @@ class CVAEEngine:
         if do_mmd:
             self._wait(ev_side)
         _lib.check(L.sca_mid_bwd(self._mid_args(B, cond_p, p_drop, eps, masks, sp, S, stride,
-                                                ws["mmd_g1"].data_ptr() if do_mmd else None), st), "mid_bwd")
+                                                ws["mmd_g1"].data_ptr() if do_mmd else None, pre0=pre0), st),
+                   "mid_bwd")
         # weight-side gradients of every middle layer: one dependency point, aux stream
         mids = [(ly, ws["z"].data_ptr() if i == 0 else ws[self.dec[i - 1].tag + ".h"].data_ptr())
                 for i, ly in enumerate(self.dec)]
@@ -982,8 +993,9 @@ class CVAEEngine:
                 self._grad_gemm(1, 1, dh, 2 * Z, h_enc, Hl, 2 * Z, Hl, B, sa, self.heads_gw)
                 self._colsum(dh, B, 2 * Z, None, 0, None, self.heads_gb.data_ptr(), sa)
         self._defer(mid_side)
-        self._layer_backward(self.enc[0], ws["x"].data_ptr(), ws["dh0"].data_ptr(), 1, 0, None, False, B, cond_p,
-                             p_drop, masks, st)
+        # da of the first layer was written by mid_bwd: only its weight-side gradients remain
+        self._layer_backward(self.enc[0], ws["x"].data_ptr(), None, 0, 0, None, False, B, cond_p, p_drop, masks, st,
+                             have_da=True)
         self._defer(self._run_tail)
         self._wait(self._flush())
         return self.losses
@@ -1177,8 +1189,8 @@ class CVAEEngine:
           * False  : launched eagerly through the normal Python path."""
         if use_graph == "auto":
             use_graph = True if B <= 2048 else "plan"
-        self.begin_step(alpha_kl, lr, eps, clip)
         if use_graph is False:
+            self.begin_step(alpha_kl, lr, eps, clip)
             self.forward_backward(row_ids, cond, B)
             if world > 1:
                 from . import distributed as sdist
@@ -1190,11 +1202,18 @@ class CVAEEngine:
                self.beta, torch.cuda.current_stream(self.device).cuda_stream)
         plans = self.__dict__.setdefault("_plans", {})
         g = plans.get(key)
-        if g is None:
-            g = plans[key] = (self._capture if use_graph is True else self._record)(B, weight_decay, wd_overrides,
-                                                                                    world > 1)
-        g["rows"].copy_(row_ids, non_blocking=True)
-        g["cond"].copy_(cond, non_blocking=True)
+        fast = (g is not None and row_ids.dtype == torch.int64 and cond.dtype == torch.int32 and row_ids.is_cuda
+                and cond.is_cuda and row_ids.is_contiguous() and cond.is_contiguous()
+                and row_ids.numel() == B and cond.numel() == B)
+        if fast:        # scalars + minibatch staging in one launch
+            self.begin_step(alpha_kl, lr, eps, clip, stage=(row_ids, g["rows"], cond, g["cond"], B))
+        else:
+            self.begin_step(alpha_kl, lr, eps, clip)
+            if g is None:
+                g = plans[key] = (self._capture if use_graph is True else self._record)(B, weight_decay,
+                                                                                        wd_overrides, world > 1)
+            g["rows"].copy_(row_ids, non_blocking=True)
+            g["cond"].copy_(cond, non_blocking=True)
         if use_graph is True:
             g["fwd"].replay()
         else:
@@ -1272,13 +1291,22 @@ class CVAEEngine:
         self._restore(snap)
         return out
 
-    def begin_step(self, alpha_kl, lr, eps=0.01, clip=0.0):
-        """Per-step scalars -> device (`hyper`), Philox step counter += 1: one tiny kernel, no host staging."""
+    def begin_step(self, alpha_kl, lr, eps=0.01, clip=0.0, stage=None):
+        """Per-step scalars -> device (`hyper`), Philox step counter += 1: one tiny kernel, no host staging.
+        `stage` = (rows_src, rows_dst, cond_src, cond_dst, B) also copies the minibatch into the static buffers of
+        a recorded plan / graph in the same launch."""
         self.adam_t += 1
         t = self.adam_t
         h = self._hyper_host
         h[0], h[1], h[2], h[3], h[4], h[5] = alpha_kl, lr, 1.0 - 0.9 ** t, math.sqrt(1.0 - 0.999 ** t), eps, clip
         st = torch.cuda.current_stream(self.device).cuda_stream
+        if stage is not None:
+            rs, rd, cs, cd, B = stage
+            _lib.check(self.lib._lib.sca_begin_step_batch(
+                self.hyper.data_ptr(), self.step_ctr.data_ptr(), float(alpha_kl), float(lr), float(h[2]),
+                float(h[3]), float(eps), float(clip), rs.data_ptr(), rd.data_ptr(), cs.data_ptr(), cd.data_ptr(),
+                int(B), st), "begin_step_batch")
+            return
         _lib.check(self.lib._lib.sca_begin_step(self.hyper.data_ptr(), self.step_ctr.data_ptr(), float(alpha_kl),
                                                 float(lr), float(h[2]), float(h[3]), float(eps), float(clip), st),
                    "begin_step")

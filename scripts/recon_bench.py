@@ -1,24 +1,41 @@
-import sys, ctypes, torch
-sys.path.insert(0, '.')
-from scarches_amd import _lib
+"""Dev probe: time the NB likelihood kernel alone (replayed from a recorded launch plan) over rows-per-workgroup."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from bench import build_trvae_params, epoch_batches
+from scarches_amd.engine import CVAEEngine
 from scarches_amd.synth import make_synthetic_csr
-st = torch.cuda.current_stream().cuda_stream
-N, G, C, B = 100000, 2000, 20, 4096
-indptr, indices, data, cond, _ = make_synthetic_csr(N, G, C, 'cuda', seed=0)
-ids = torch.randint(0, N, (B,), device='cuda'); c = cond[ids]; o = torch.argsort(c, stable=True); ids, c = ids[o].contiguous(), c[o].contiguous()
-logits0 = torch.randn(B, G, device='cuda'); sf = torch.rand(B, device='cuda') * 3000 + 500
-tabt = torch.exp(torch.randn(C, G, device='cuda')); tabl = torch.log(tabt + 1e-8)
-row_ll = torch.empty(B, device='cuda'); dth = torch.zeros(C, G, device='cuda'); db = torch.zeros(G, device='cuda')
-for variant in sys.argv[1:]:
-    lib = ctypes.CDLL(f'scarches_amd/csrc/libsca_{variant}.so')
-    fn = lib.sca_recon_rows; fn.argtypes = _lib.SIGNATURES['sca_recon_rows']
-    for rpb in (1, 2, 4, 8):
-        logits = logits0.clone()
-        for _ in range(2):
-            fn(0, logits.data_ptr(), G, None, indptr.data_ptr(), indices.data_ptr(), data.data_ptr(), ids.data_ptr(), sf.data_ptr(), c.data_ptr(), tabt.data_ptr(), tabl.data_ptr(), B, G, C, rpb, row_ll.data_ptr(), dth.data_ptr(), db.data_ptr(), None, 1, st)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            fn(0, logits.data_ptr(), G, None, indptr.data_ptr(), indices.data_ptr(), data.data_ptr(), ids.data_ptr(), sf.data_ptr(), c.data_ptr(), tabt.data_ptr(), tabl.data_ptr(), B, G, C, rpb, row_ll.data_ptr(), dth.data_ptr(), db.data_ptr(), None, 1, st)
-        e1.record(); torch.cuda.synchronize()
-        print(f"{variant:14s} rpb={rpb}: {e0.elapsed_time(e1)/10*1e3:.1f} us")
+
+dev = torch.device("cuda", 0)
+G, C, Z, H = 2000, 20, 10, [128, 128]
+indptr, indices, data, cond_all, _ = make_synthetic_csr(100_000, G, C, dev, seed=1000)
+print("max count", data.max().item(), "frac > 16:", (data > 16).float().mean().item(), flush=True)
+P = build_trvae_params(G, C, H, Z)
+gen = torch.Generator(device=dev); gen.manual_seed(1)
+for B in (4096, 16384):
+    spec = dict(G=G, C=C, H=H, Z=Z, recon="nb", use_bn=False, use_ln=True, use_mmd=True, mmd_on="z", boundary=None,
+                beta=1.0, dr_rate=0.05, seed=2020)
+    eng = CVAEEngine(spec, P, dev)
+    eng.bind_csr(indptr, indices, data)
+    ids, cs = epoch_batches(cond_all, 2, B, gen)
+    eng.train_step(ids[0], cs[0], B, 0.5, 1e-3, use_graph="plan")
+    torch.cuda.synchronize()
+    plan = next(iter(eng._plans.values()))["fwd"]
+    for name in ("sca_recon_rows", "sca_csr_gather_dense"):
+        hits = [(fn, args) for fn, args, _ in plan if getattr(fn, "__name__", "") == name]
+        if not hits:
+            print("no", name, [getattr(f, "__name__", "?") for f, _, _ in plan][:40]); continue
+        fn, args = hits[0]
+        variants = (1, 2, 4, 8, 16) if name == "sca_recon_rows" else (None,)
+        for rpb in variants:
+            a = list(args)
+            if rpb is not None:
+                a[15] = rpb
+            for _ in range(2):
+                fn(*a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn(*a)
+            e1.record(); torch.cuda.synchronize()
+            print(f"B={B} {name} rpb={rpb}: {e0.elapsed_time(e1) / 10 * 1e3:.1f} us", flush=True)
