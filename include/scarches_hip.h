@@ -42,6 +42,19 @@ int sca_dense_gather_rows(const float* X, int ldX, const int64_t* row_ids, int B
 int sca_gemm_splitk_heuristic(int M, int N, int K);
 int sca_gemm_f32(int amode, int bmode, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
                  int N, int K, int splitk, long long slab_stride, const float* bias, void* stream);
+/* Several weight-gradient GEMMs dW = dY^T X in ONE launch (torch autograd issues one mm per nn.Linear weight in
+ * CondLayers/Encoder/Decoder backward, scarches/models/trvae/modules.py:21-27,52-97,124-208).  Every job must have
+ * amode == bmode == 1; 64x64 tiles; each job has its own split-K count and slab stride (sum the slabs as for
+ * sca_gemm_f32).  At most sca_gemm_group_max_jobs() jobs. */
+typedef struct {
+    int32_t amode, bmode;
+    const float* A; const float* B; float* C;
+    int32_t lda, ldb, ldc, M, N, K, splitk, pad;
+    long long slab_stride;
+} sca_gemm_job;
+int sca_gemm_group_max_jobs(void);
+int sca_gemm_group_f32(const sca_gemm_job* jobs, int n, void* stream);
+
 /* Same with an explicit block tile (64*tile_wm) x (64*tile_wn), tile_w* in {1,2}; 0 = automatic (tuning hook). */
 int sca_gemm_f32_cfg(int amode, int bmode, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
                      int N, int K, int splitk, long long slab_stride, const float* bias, int tile_wm, int tile_wn,

@@ -26,6 +26,13 @@ class TailJob(C.Structure):
                 ("B", C.c_int32), ("H", C.c_int32), ("C", C.c_int32), ("pad", C.c_int32)]
 
 
+class GemmJob(C.Structure):
+    """sca_gemm_job of include/scarches_hip.h."""
+    _fields_ = [("amode", C.c_int32), ("bmode", C.c_int32), ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+                ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32), ("M", C.c_int32), ("N", C.c_int32),
+                ("K", C.c_int32), ("splitk", C.c_int32), ("pad", C.c_int32), ("slab_stride", C.c_longlong)]
+
+
 class MidLayer(C.Structure):
     """sca_mid_layer of include/scarches_hip.h."""
     _fields_ = [("W", C.c_void_p), ("bias", C.c_void_p), ("Wc", C.c_void_p), ("mask", C.c_void_p),
@@ -58,6 +65,8 @@ SIGNATURES = {
     "sca_gemm_f32": [I, I, P, I, P, I, P, I, I, I, I, I, LL, P, P],
     "sca_gemm_f32_cfg": [I, I, P, I, P, I, P, I, I, I, I, I, LL, P, I, I, P],
     "sca_splitk_reduce": [P, I, LL, P, LL, P],
+    "sca_gemm_group_max_jobs": [],
+    "sca_gemm_group_f32": [P, I, P],
     "sca_layer_fwd": [P, I, LL, I, I, P, P, I, P, P, I, I, I, F, P, U64, U32, P, P, P, P, P],
     "sca_layer_bwd": [P, I, LL, P, I, I, P, P, I, I, F, P, U64, U32, P, P, P],
     "sca_cond_colsum": [P, I, I, P, I, P, P, P, P],

@@ -43,6 +43,8 @@ struct GemmArgs {
     int k_chunk;         // multiple of BK (16)
     long long slab_stride;
     int tiles_m;
+    int nsplit;          // number of split-K slabs of this GEMM (the bias is only added when it is 1)
+    int vec;             // grouped launches: this job's operands allow 16-byte loads
 };
 
 // Load one (64*W)(rows) x BK(k) operand tile into W*BK/16 float4 registers per thread.
@@ -106,14 +108,12 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (
 }
 
 template <int AMODE, int BMODE, bool VEC, int WM, int WN>
-__global__ __launch_bounds__(256, GEMM_OCC) void gemm_f32_kernel(const GemmArgs a) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& a, int tile, int zs, float* __restrict__ lds) {
     constexpr int BM = 64 * WM, BN = 64 * WN, LDA = BM + 4, LDB = BN + 4;
     constexpr int ASZ = BK * LDA, BSZ = BK * LDB;            // LDS image: [A0 | A1 | B0 | B1]
-    __shared__ __attribute__((aligned(16))) float lds[2 * (ASZ + BSZ)];
 
-    const int tile = blockIdx.x;
     const int m0 = (tile % a.tiles_m) * BM, n0 = (tile / a.tiles_m) * BN;
-    const int kbeg = blockIdx.z * a.k_chunk;
+    const int kbeg = zs * a.k_chunk;
     const int kend = min(a.K, kbeg + a.k_chunk);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wm = w >> 1, wn = w & 1, l31 = lane & 31, half = lane >> 5;
@@ -169,8 +169,8 @@ __global__ __launch_bounds__(256, GEMM_OCC) void gemm_f32_kernel(const GemmArgs 
         __syncthreads();
     }
 
-    float* C = a.C + (long long)blockIdx.z * a.slab_stride;
-    const bool add_bias = a.bias != nullptr && gridDim.z == 1;
+    float* C = a.C + (long long)zs * a.slab_stride;
+    const bool add_bias = a.bias != nullptr && a.nsplit == 1;
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -184,6 +184,33 @@ __global__ __launch_bounds__(256, GEMM_OCC) void gemm_f32_kernel(const GemmArgs 
                 if (m < a.M) C[(long long)m * a.ldc + n] = acc[i][j][r] + bv;
             }
         }
+}
+
+template <int AMODE, int BMODE, bool VEC, int WM, int WN>
+__global__ __launch_bounds__(256, GEMM_OCC) void gemm_f32_kernel(const GemmArgs a) {
+    constexpr int LDSZ = 2 * BK * (64 * WM + 4 + 64 * WN + 4);
+    __shared__ __attribute__((aligned(16))) float lds[LDSZ];
+    gemm_body<AMODE, BMODE, VEC, WM, WN>(a, blockIdx.x, blockIdx.z, lds);
+}
+
+// Several independent GEMMs in ONE launch (the weight-gradient GEMMs dY^T X of a step: same operand modes, 64x64
+// tiles, each with its own split-K): a workgroup looks its job up from the cumulative workgroup counts.
+constexpr int GROUP_MAX = 8;
+struct GroupArgs {
+    GemmArgs job[GROUP_MAX];
+    int wg_begin[GROUP_MAX + 1];
+    int tiles[GROUP_MAX];        // output tiles of a job (workgroups per split)
+    int n;
+};
+__global__ __launch_bounds__(256, GEMM_OCC) void gemm_group_kernel(const GroupArgs g) {
+    constexpr int LDSZ = 2 * BK * (64 + 4 + 64 + 4);
+    __shared__ __attribute__((aligned(16))) float lds[LDSZ];
+    int j = 0;
+    while (j + 1 < g.n && (int)blockIdx.x >= g.wg_begin[j + 1]) ++j;
+    const int local = blockIdx.x - g.wg_begin[j];
+    const int zs = local / g.tiles[j];
+    if (g.job[j].vec) gemm_body<1, 1, true, 1, 1>(g.job[j], local - zs * g.tiles[j], zs, lds);
+    else gemm_body<1, 1, false, 1, 1>(g.job[j], local - zs * g.tiles[j], zs, lds);
 }
 
 // Sum S slabs into dst: dst[i] = sum_s slabs[s*stride + i].  4 independent accumulation chains keep several
@@ -234,7 +261,7 @@ static GemmPlan plan_gemm(int M, int N, int K) {
     const long long t11 = (long long)((M + 63) / 64) * ((N + 63) / 64);
     GemmPlan p{1, 1, 1};
     long long tiles = t11;
-    if (t11 >= 4096 && M > 64 && N > 64) {
+    if (t11 >= 4096 && M > 64 && N > 64 && K >= 256) {     // short K: a 128x128 tile never amortises its prologue
         p.wm = p.wn = 2;
         tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
     }
@@ -277,6 +304,8 @@ extern "C" int sca_gemm_f32_cfg(int amode, int bmode, const float* A, int lda, c
     const int kt_per = (kt + splitk - 1) / splitk;
     a.k_chunk = kt_per * BK;
     a.slab_stride = slab_stride;
+    a.nsplit = splitk;
+    a.vec = 0;
     a.tiles_m = (M + 64 * tile_wm - 1) / (64 * tile_wm);
     const int tiles_n = (N + 64 * tile_wn - 1) / (64 * tile_wn);
     const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
@@ -295,6 +324,47 @@ extern "C" int sca_gemm_f32(int amode, int bmode, const float* A, int lda, const
     GemmPlan p = plan_gemm(M, N, K);
     return sca_gemm_f32_cfg(amode, bmode, A, lda, B, ldb, C, ldc, M, N, K, splitk, slab_stride, bias, p.wm, p.wn,
                             stream);
+}
+
+extern "C" {
+typedef struct {
+    int32_t amode, bmode;        // must both be 1 (A^T B: contraction over the rows of both operands)
+    const float* A; const float* B; float* C;
+    int32_t lda, ldb, ldc, M, N, K, splitk, pad;
+    long long slab_stride;
+} sca_gemm_job;
+}
+
+extern "C" int sca_gemm_group_max_jobs(void) { return GROUP_MAX; }
+
+extern "C" int sca_gemm_group_f32(const sca_gemm_job* jobs, int n, void* stream) {
+    if (n <= 0) return 0;
+    if (n > GROUP_MAX) return -2;
+    GroupArgs g;
+    int wg = 0;
+    for (int j = 0; j < n; ++j) {
+        const sca_gemm_job& J = jobs[j];
+        if (J.amode != 1 || J.bmode != 1) return -2;
+        if (J.M <= 0 || J.N <= 0 || J.K <= 0 || J.splitk < 1) return -1;
+        GemmArgs& a = g.job[j];
+        a.A = J.A; a.B = J.B; a.C = J.C; a.bias = nullptr;
+        a.lda = J.lda; a.ldb = J.ldb; a.ldc = J.ldc;
+        a.M = J.M; a.N = J.N; a.K = J.K;
+        const int kt = (J.K + BK - 1) / BK;
+        a.k_chunk = ((kt + J.splitk - 1) / J.splitk) * BK;
+        a.slab_stride = J.slab_stride;
+        a.nsplit = J.splitk;
+        a.tiles_m = (J.M + 63) / 64;
+        g.tiles[j] = a.tiles_m * ((J.N + 63) / 64);
+        g.wg_begin[j] = wg;
+        wg += g.tiles[j] * J.splitk;
+        a.vec = (J.lda % 4 == 0) && (J.ldb % 4 == 0) && (((uintptr_t)J.A | (uintptr_t)J.B) % 16 == 0);
+    }
+    g.wg_begin[n] = wg;
+    g.n = n;
+    hipLaunchKernelGGL(gemm_group_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, g);
+    SCA_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int sca_splitk_reduce(const float* slabs, int S, long long slab_stride, float* dst, long long n,

@@ -35,7 +35,7 @@ class _Layer:
         self.bn = bn        # state-dict prefix of the BatchNorm1d after this Linear (use_bn), e.g. "encoder.FC.N0"
 
 
-_QUERIES = {"sca_mid_max_width", "sca_grad_tail_max_jobs", "sca_gemm_splitk_heuristic", "sca_mmd_num_slabs", "sca_mmd_num_partials", "sca_hsic_workspace_floats",
+_QUERIES = {"sca_mid_max_width", "sca_grad_tail_max_jobs", "sca_gemm_group_max_jobs", "sca_gemm_splitk_heuristic", "sca_mmd_num_slabs", "sca_mmd_num_partials", "sca_hsic_workspace_floats",
             "sca_proto_workspace_bytes", "sca_abi_version", "sca_device_name"}
 
 
@@ -466,7 +466,10 @@ class CVAEEngine:
         """Re-issue recorded GEMM launches (bench.py roofline leg: same shapes, same buffers, nothing else)."""
         st = torch.cuda.current_stream(self.device).cuda_stream
         for args in calls:
-            _lib.check(self.lib.sca_gemm_f32(*args, st), "gemm")
+            if args[0] == "group":
+                _lib.check(self.lib.sca_gemm_group_f32(args[1], len(args[1]), st), "gemm_group")
+            else:
+                _lib.check(self.lib.sca_gemm_f32(*args, st), "gemm")
 
     def _gemm_to(self, am, bm, A, lda, Bm, ldb, M, N, K, st, dst, slab_key="slab"):
         """GEMM whose (reduced) result lands in the contiguous tensor `dst` [M, N]."""
@@ -493,10 +496,40 @@ class CVAEEngine:
         if slab is None or slab.numel() < S * M * N:
             slab = self.ws[key] = torch.empty(S * M * N, dtype=torch.float32, device=self.device)
         args = (am, bm, A, lda, Bm, ldb, slab.data_ptr(), N, M, N, K, S, M * N, None)
+        self._tail_jobs.append((0, S, M * N, slab.data_ptr(), dst.data_ptr(), M * N, 0, 0, 0, 0, 0))
+        group = getattr(self, "_gg_jobs", None)
+        if group is not None and am == 1 and bm == 1:      # joins the grouped launch (_launch_group)
+            group.append(args)
+            return
         if rec is not None:
             rec.append(args)
         _lib.check(L.sca_gemm_f32(*args, st), "gemm")
-        self._tail_jobs.append((0, S, M * N, slab.data_ptr(), dst.data_ptr(), M * N, 0, 0, 0, 0, 0))
+
+    def _launch_group(self, jobs, st):
+        """Weight-gradient GEMMs collected by _grad_gemm -> sca_gemm_group_f32 launches (one for up to 8 jobs)."""
+        if not jobs:
+            return
+        rec = getattr(self, "record_gemms", None)
+        cache = self.__dict__.setdefault("_gg_cache", {})
+        key = tuple(jobs)
+        arrs = cache.get(key)
+        if arrs is None:
+            if len(cache) > 64:
+                cache.clear()
+            mx = self.lib.sca_gemm_group_max_jobs()
+            arrs = []
+            for lo in range(0, len(jobs), mx):
+                chunk = jobs[lo:lo + mx]
+                arr = (_lib.GemmJob * len(chunk))()
+                for j, (am, bm, A, lda, Bm, ldb, Cp, ldc, M, N, K, S, stride, _) in zip(arr, chunk):
+                    j.amode, j.bmode, j.A, j.B, j.C = am, bm, A, Bm, Cp
+                    j.lda, j.ldb, j.ldc, j.M, j.N, j.K, j.splitk, j.slab_stride = lda, ldb, ldc, M, N, K, S, stride
+                arrs.append((arr, tuple(chunk)))
+            cache[key] = arrs
+        for arr, chunk in arrs:
+            if rec is not None:
+                rec.append(("group", arr, chunk))
+            _lib.check(self.lib.sca_gemm_group_f32(arr, len(arr), st), "gemm_group")
 
     def _colsum(self, da, B, H, cond_p, C, dWc, db, st):
         """db[h] = sum_b da[b][h]; dWc[h][c] = sum over rows of condition c (tail job; direct launch for huge C)."""
@@ -790,7 +823,7 @@ class CVAEEngine:
         self._backward_latent_encoder(B, cond_p, p_drop, masks, st, sp, S, stride, dz2, S2)
 
     def _layer_backward(self, ly, a_prev, sp, S, stride, extra, need_dx, B, cond_p, p_drop, masks, st,
-                        have_da=False):
+                        have_da=False, side_out=None):
         """Gradient through one Linear(+cond) -> norm -> ReLU -> dropout block: `da` and (need_dx) the dX GEMM slabs for
         the layer below on the main stream; the weight / bias / condition-weight gradients are deferred to the aux
         stream."""
@@ -836,7 +869,10 @@ class CVAEEngine:
                 self._colsum(da, B, ly.n_out, cond_p, C, Gd[ly.wc].data_ptr() if need_c else None,
                              Gd[ly.b].data_ptr() if need_b else None, sa)
         if need_w or need_b or need_c or need_e:
-            self._defer(side)
+            if side_out is not None:
+                side_out.append(side)
+            else:
+                self._defer(side)
         if need_dx:
             return self._gemm(0, 1, da, ly.n_out, P[ly.w].data_ptr(), ly.n_in, B, ly.n_in, ly.n_out, st)
         return None, 0, 0
@@ -992,10 +1028,21 @@ class CVAEEngine:
             if any(T[k] for k in self.heads_names):
                 self._grad_gemm(1, 1, dh, 2 * Z, h_enc, Hl, 2 * Z, Hl, B, sa, self.heads_gw)
                 self._colsum(dh, B, 2 * Z, None, 0, None, self.heads_gb.data_ptr(), sa)
-        self._defer(mid_side)
         # da of the first layer was written by mid_bwd: only its weight-side gradients remain
+        sides = []
         self._layer_backward(self.enc[0], ws["x"].data_ptr(), None, 0, 0, None, False, B, cond_p, p_drop, masks, st,
-                             have_da=True)
+                             have_da=True, side_out=sides)
+
+        def weight_side(sa):      # every dY^T X of the encoder / middle layers: ONE grouped GEMM launch
+            self._gg_jobs = []
+            try:
+                for f in sides:
+                    f(sa)         # the wide first-layer GEMM first: its tiles fill the chip, the small ones tuck in
+                mid_side(sa)
+            finally:
+                jobs, self._gg_jobs = self._gg_jobs, None
+            self._launch_group(jobs, sa)
+        self._defer(weight_side)
         self._defer(self._run_tail)
         self._wait(self._flush())
         return self.losses
