@@ -16,9 +16,11 @@
 // (exact fp32: bit-identical to an fmaf chain in k order, so parity with the CPU reference is limited only
 // by summation order).  LDS tiles are k-major with a +4 pad: fragment reads are conflict-free ds_read_b32,
 // transposing stores of the k-contiguous operands are 2-way (free on ds_write_b32).  Global->LDS staging is
-// register-prefetched one tile ahead (double-buffered LDS, one barrier per k-step).
+// register-prefetched, the k loop runs on a three-stage LDS ring with double-buffered fragment registers (one barrier
+// per k-step; see gemm_body).
 // Split-K (gridDim.z) writes per-split slabs; the consumer kernel sums them (deterministic, no atomics).
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -31,6 +33,7 @@ namespace {
 #define GEMM_BK 16
 #endif
 constexpr int BK = GEMM_BK;
+constexpr int NSTAGE = 3;      // LDS stages of the k pipeline (see gemm_body)
 // block tile = (64*WM) x (64*WN): 2x2 waves, each wave WM x WN MFMA tiles of 32x32.  LDS row stride = rows + 4.
 
 struct GemmArgs {
@@ -110,7 +113,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (
 template <int AMODE, int BMODE, bool VEC, int WM, int WN>
 __device__ __forceinline__ void gemm_body(const GemmArgs& a, int tile, int zs, float* __restrict__ lds) {
     constexpr int BM = 64 * WM, BN = 64 * WN, LDA = BM + 4, LDB = BN + 4;
-    constexpr int ASZ = BK * LDA, BSZ = BK * LDB;            // LDS image: [A0 | A1 | B0 | B1]
+    constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
 
     const int m0 = (tile % a.tiles_m) * BM, n0 = (tile / a.tiles_m) * BN;
     const int kbeg = zs * a.k_chunk;
@@ -128,45 +131,72 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int tile, int zs, f
 
     const int nk = (kend - kbeg + BK - 1) / BK;
     float4 ra[WM * BK / 16], rb[WN * BK / 16];
+    // LDS image: three A stages then three B stages.  Stage s holds k-tile kt with kt % 3 == s: while tile kt feeds
+    // the MFMAs, the fragments of tile kt+1 (complete since the previous barrier) are read into the second fragment
+    // register set BETWEEN those MFMAs, and tile kt+2 travels global -> registers -> stage (kt+2) % 3.  The LDS
+    // latency at k-step boundaries - a third of the loop with two stages - is hidden; one barrier per k-step still
+    // suffices (the stage written in step kt was last read in step kt-2).
+    float* As = lds;
+    float* Bs = lds + NSTAGE * ASZ;
+    const int aoff = half * LDA + wm * (32 * WM) + l31, boff = half * LDB + wn * (32 * WN) + l31;
+    float av[2][BK / 2][WM], bv[2][BK / 2][WN];
     if (nk > 0) {
         load_tile<AMODE, VEC, WM>(a.A, a.lda, a.M, m0, kbeg, kend, ra);
         load_tile<BMODE, VEC, WN>(a.B, a.ldb, a.N, n0, kbeg, kend, rb);
-        store_tile<AMODE, WM>(lds, ra);
-        store_tile<BMODE, WN>(lds + 2 * ASZ, rb);
+        store_tile<AMODE, WM>(As, ra);
+        store_tile<BMODE, WN>(Bs, rb);
+    }
+    if (nk > 1) {
+        load_tile<AMODE, VEC, WM>(a.A, a.lda, a.M, m0, kbeg + BK, kend, ra);
+        load_tile<BMODE, VEC, WN>(a.B, a.ldb, a.N, n0, kbeg + BK, kend, rb);
+        store_tile<AMODE, WM>(As + ASZ, ra);
+        store_tile<BMODE, WN>(Bs + BSZ, rb);
     }
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            load_tile<AMODE, VEC, WM>(a.A, a.lda, a.M, m0, kbeg + (kt + 1) * BK, kend, ra);
-            load_tile<BMODE, VEC, WN>(a.B, a.ldb, a.N, n0, kbeg + (kt + 1) * BK, kend, rb);
-        }
-        const float* Ac = lds + cur * ASZ + half * LDA + wm * (32 * WM) + l31;
-        const float* Bc = lds + 2 * ASZ + cur * BSZ + half * LDB + wn * (32 * WN) + l31;
-        // all fragment reads of the k-step are issued up front (counted lgkmcnt waits), so the 8*WM*WN MFMAs
-        // run back to back instead of stalling on LDS latency after every k-pair
-        float av[BK / 2][WM], bv[BK / 2][WN];
+    if (nk > 0) {
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
 #pragma unroll
-            for (int i = 0; i < WM; ++i) av[kk][i] = Ac[(2 * kk) * LDA + 32 * i];
+            for (int i = 0; i < WM; ++i) av[0][kk][i] = As[aoff + (2 * kk) * LDA + 32 * i];
 #pragma unroll
-            for (int j = 0; j < WN; ++j) bv[kk][j] = Bc[(2 * kk) * LDB + 32 * j];
+            for (int j = 0; j < WN; ++j) bv[0][kk][j] = Bs[boff + (2 * kk) * LDB + 32 * j];
         }
-        __builtin_amdgcn_sched_barrier(0);      // keep the reads above: hipcc otherwise sinks them next to each MFMA
+    }
+    // one k-step: MFMAs on fragment set P, fragment reads of the next tile into set 1-P interleaved among them
+    auto kstep = [&](auto PP, int kt) {
+        constexpr int P = decltype(PP)::value;
+        const bool more2 = kt + 2 < nk, more1 = kt + 1 < nk;
+        if (more2) {
+            load_tile<AMODE, VEC, WM>(a.A, a.lda, a.M, m0, kbeg + (kt + 2) * BK, kend, ra);
+            load_tile<BMODE, VEC, WN>(a.B, a.ldb, a.N, n0, kbeg + (kt + 2) * BK, kend, rb);
+        }
+        const int s1 = (kt + 1) % NSTAGE;
+        const float* An = As + s1 * ASZ + aoff;
+        const float* Bn = Bs + s1 * BSZ + boff;
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][i], bv[kk][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[P][kk][i], bv[P][kk][j], acc[i][j], 0, 0, 0);
+            if (more1) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) av[1 - P][kk][i] = An[(2 * kk) * LDA + 32 * i];
+#pragma unroll
+                for (int j = 0; j < WN; ++j) bv[1 - P][kk][j] = Bn[(2 * kk) * LDB + 32 * j];
+            }
         }
-        if (kt + 1 < nk) {
-            store_tile<AMODE, WM>(lds + (cur ^ 1) * ASZ, ra);
-            store_tile<BMODE, WN>(lds + 2 * ASZ + (cur ^ 1) * BSZ, rb);
+        if (more2) {
+            const int s2 = (kt + 2) % NSTAGE;
+            store_tile<AMODE, WM>(As + s2 * ASZ, ra);
+            store_tile<BMODE, WN>(Bs + s2 * BSZ, rb);
         }
         __syncthreads();
+    };
+    for (int kt = 0; kt < nk; kt += 2) {
+        kstep(std::integral_constant<int, 0>{}, kt);
+        if (kt + 1 < nk) kstep(std::integral_constant<int, 1>{}, kt + 1);
     }
 
     float* C = a.C + (long long)zs * a.slab_stride;
@@ -188,7 +218,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int tile, int zs, f
 
 template <int AMODE, int BMODE, bool VEC, int WM, int WN>
 __global__ __launch_bounds__(256, GEMM_OCC) void gemm_f32_kernel(const GemmArgs a) {
-    constexpr int LDSZ = 2 * BK * (64 * WM + 4 + 64 * WN + 4);
+    constexpr int LDSZ = NSTAGE * BK * (64 * WM + 4 + 64 * WN + 4);
     __shared__ __attribute__((aligned(16))) float lds[LDSZ];
     gemm_body<AMODE, BMODE, VEC, WM, WN>(a, blockIdx.x, blockIdx.z, lds);
 }
@@ -203,7 +233,7 @@ struct GroupArgs {
     int n;
 };
 __global__ __launch_bounds__(256, GEMM_OCC) void gemm_group_kernel(const GroupArgs g) {
-    constexpr int LDSZ = 2 * BK * (64 + 4 + 64 + 4);
+    constexpr int LDSZ = NSTAGE * BK * (64 + 4 + 64 + 4);
     __shared__ __attribute__((aligned(16))) float lds[LDSZ];
     int j = 0;
     while (j + 1 < g.n && (int)blockIdx.x >= g.wg_begin[j + 1]) ++j;
