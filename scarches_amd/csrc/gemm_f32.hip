@@ -48,6 +48,7 @@ struct GemmArgs {
     int tiles_m;
     int nsplit;          // number of split-K slabs of this GEMM (the bias is only added when it is 1)
     int vec;             // grouped launches: this job's operands allow 16-byte loads
+    int tiles_n, n_fast; // tile order (see gemm_body)
 };
 
 // Load one (64*W)(rows) x BK(k) operand tile into W*BK/16 float4 registers per thread.
@@ -115,7 +116,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int tile, int zs, f
     constexpr int BM = 64 * WM, BN = 64 * WN, LDA = BM + 4, LDB = BN + 4;
     constexpr int ASZ = BK * LDA, BSZ = BK * LDB;
 
-    const int m0 = (tile % a.tiles_m) * BM, n0 = (tile / a.tiles_m) * BN;
+    // tile order: the dimension with more tiles varies fastest, so the few tiles that share the LARGE operand
+    // (e.g. the two 64-row tiles of dW = da^T x that both stream x) are a multiple of 8 workgroups apart and land on
+    // the same XCD - its L2 then serves the second read instead of the fabric
+    const int tm = a.n_fast ? tile / a.tiles_n : tile % a.tiles_m;
+    const int tn = a.n_fast ? tile % a.tiles_n : tile / a.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
     const int kbeg = zs * a.k_chunk;
     const int kend = min(a.K, kbeg + a.k_chunk);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -338,6 +344,8 @@ extern "C" int sca_gemm_f32_cfg(int amode, int bmode, const float* A, int lda, c
     a.vec = 0;
     a.tiles_m = (M + 64 * tile_wm - 1) / (64 * tile_wm);
     const int tiles_n = (N + 64 * tile_wn - 1) / (64 * tile_wn);
+    a.tiles_n = tiles_n;
+    a.n_fast = tiles_n > a.tiles_m;
     const bool vec = (lda % 4 == 0) && (ldb % 4 == 0) && (((uintptr_t)A | (uintptr_t)B) % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
     if (amode == 0 && bmode == 0) launch_gemm_tile<0, 0>(a, tile_wm, tile_wn, tiles_n, splitk, vec, st);
@@ -385,7 +393,9 @@ extern "C" int sca_gemm_group_f32(const sca_gemm_job* jobs, int n, void* stream)
         a.slab_stride = J.slab_stride;
         a.nsplit = J.splitk;
         a.tiles_m = (J.M + 63) / 64;
-        g.tiles[j] = a.tiles_m * ((J.N + 63) / 64);
+        a.tiles_n = (J.N + 63) / 64;
+        a.n_fast = a.tiles_n > a.tiles_m;
+        g.tiles[j] = a.tiles_m * a.tiles_n;
         g.wg_begin[j] = wg;
         wg += g.tiles[j] * J.splitk;
         a.vec = (J.lda % 4 == 0) && (J.ldb % 4 == 0) && (((uintptr_t)J.A | (uintptr_t)J.B) % 16 == 0);
