@@ -1,0 +1,186 @@
+"""Size-independent properties of the HIP train step at the benchmark's full minibatch size (cfg2: 8192 cells x 2000
+HVG, 20 conditions, NB, MMD on z, hidden [128, 128], Z = 10) - where the CPU oracle no longer finishes in seconds:
+
+  * two independent implementations agree: fused middle kernels + grouped GEMM vs one GEMM / epilogue launch per layer;
+  * launch modes agree: eager launches, the recorded launch plan and the HIP graph give the same trajectory;
+  * row-permutation invariance: the step's losses and gradients do not depend on the order of the cells;
+  * batch additivity of the likelihood + KL gradients (MMD off): g(B) = (n1 g(B1) + n2 g(B2)) / B;
+  * the CSR gather against torch's own sparse->dense path, the MMD (value + gradient) against a plain torch fp64
+    evaluation of the reference's pairwise formula (models/trvae/losses.py:166-270).
+Tolerances are the north-star ones (rel 1e-5 on losses, 5e-5 max-norm on gradients) unless stated."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G, C, Z, H, B = 2000, 20, 10, [128, 128], 8192
+
+
+@pytest.fixture(scope="module")
+def data():
+    from scarches_amd.synth import make_synthetic_csr
+    dev = torch.device("cuda", 0)
+    indptr, indices, vals, cond_all, _ = make_synthetic_csr(40_000, G, C, dev, seed=77)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    rows = torch.randperm(40_000, generator=gen, device=dev)[:B]
+    cond = cond_all[rows]
+    order = torch.argsort(cond, stable=True)
+    return dict(csr=(indptr, indices, vals), rows=rows[order].contiguous(), cond=cond[order].contiguous().to(torch.int32))
+
+
+def make_engine(data, **over):
+    from bench import build_trvae_params
+    from scarches_amd.engine import CVAEEngine
+    spec = dict(G=G, C=C, H=H, Z=Z, recon="nb", use_bn=False, use_ln=True, use_mmd=True, mmd_on="z", boundary=None,
+                beta=1.0, dr_rate=0.05, seed=2020)
+    spec.update(over)
+    eng = CVAEEngine(spec, build_trvae_params(G, C, H, Z), "cuda:0")
+    eng.bind_csr(*data["csr"])
+    return eng
+
+
+def grads(eng):
+    return {k: eng.g[k].detach().clone() for k in eng.names}
+
+
+def assert_grads_close(ga, gb, rtol=5e-5):
+    gmax = max(float(v.abs().max()) for v in gb.values())
+    for k in gb:
+        scale = max(float(gb[k].abs().max()), 2e-6 * gmax)
+        err = float((ga[k] - gb[k]).abs().max())
+        assert err <= rtol * scale, (k, err, scale)
+
+
+def test_fused_and_unfused_paths_agree(data):
+    a, b = make_engine(data, fused_mid=True), make_engine(data, fused_mid=False)
+    assert a.use_fused_mid and not b.use_fused_mid
+    eps = torch.randn(B, Z, device="cuda")
+    for e in (a, b):
+        e.begin_step(alpha_kl=0.5, lr=1e-3)
+        e.forward_backward(data["rows"], data["cond"], B, eps=eps)
+    torch.cuda.synchronize()
+    la, lb = a.losses.cpu().numpy(), b.losses.cpu().numpy()
+    assert np.all(np.abs(la[:3] - lb[:3]) <= 1e-5 * np.abs(lb[:3]) + 1e-7), (la, lb)
+    assert_grads_close(grads(a), grads(b))
+
+
+def test_launch_modes_agree(data):
+    ref = None
+    for mode in (False, "plan", True):
+        eng = make_engine(data)
+        for _ in range(3):
+            eng.train_step(data["rows"], data["cond"], B, 0.5, 1e-3, use_graph=mode)
+        torch.cuda.synchronize()
+        out = (eng.losses.cpu().numpy().copy(), eng.flat_p.detach().clone())
+        if ref is None:
+            ref = out
+            continue
+        # same kernels, same Philox streams; float atomics (theta / bias / MMD columns) may reorder between runs
+        assert np.all(np.abs(out[0][:3] - ref[0][:3]) <= 1e-5 * np.abs(ref[0][:3])), (mode, out[0], ref[0])
+        assert float((out[1] - ref[1]).abs().max()) <= 1e-5 * float(ref[1].abs().max()), mode
+
+
+def test_row_permutation_invariance(data):
+    eps = torch.randn(B, Z, device="cuda")
+    perm = torch.randperm(B, device="cuda")
+    a, b = make_engine(data, dr_rate=0.0), make_engine(data, dr_rate=0.0)
+    a.begin_step(alpha_kl=0.5, lr=1e-3)
+    a.forward_backward(data["rows"], data["cond"], B, eps=eps)
+    b.begin_step(alpha_kl=0.5, lr=1e-3)
+    b.forward_backward(data["rows"][perm].contiguous(), data["cond"][perm].contiguous(), B, eps=eps[perm].contiguous())
+    torch.cuda.synchronize()
+    la, lb = a.losses.cpu().numpy(), b.losses.cpu().numpy()
+    assert abs(la[0] - lb[0]) <= 1e-5 * abs(la[0]) and abs(la[1] - lb[1]) <= 1e-5 * abs(la[1]), (la, lb)
+    # the MMD is a sum of O(10) block means with alternating signs: rel 1e-5 of the largest partial sum
+    assert abs(la[2] - lb[2]) <= 1e-4 * abs(la[2]) + 1e-5, (la, lb)
+    assert_grads_close(grads(b), grads(a), rtol=1e-4)
+
+
+def test_batch_additivity_without_mmd(data):
+    eps = torch.randn(B, Z, device="cuda")
+    n1 = 3000
+    full = make_engine(data, use_mmd=False, dr_rate=0.0)
+    full.begin_step(alpha_kl=0.5, lr=1e-3)
+    full.forward_backward(data["rows"], data["cond"], B, eps=eps)
+    gf, lf = grads(full), full.losses.cpu().numpy().copy()
+    acc, lsum = None, np.zeros(2)
+    for lo, hi in ((0, n1), (n1, B)):
+        e = make_engine(data, use_mmd=False, dr_rate=0.0)
+        e.begin_step(alpha_kl=0.5, lr=1e-3)
+        n = hi - lo
+        e.forward_backward(data["rows"][lo:hi].contiguous(), data["cond"][lo:hi].contiguous(), n,
+                           eps=eps[lo:hi].contiguous())
+        torch.cuda.synchronize()
+        w = n / B
+        lsum += w * e.losses.cpu().numpy()[:2]
+        g = grads(e)
+        acc = {k: w * v for k, v in g.items()} if acc is None else {k: acc[k] + w * g[k] for k in g}
+    assert np.all(np.abs(lsum - lf[:2]) <= 1e-5 * np.abs(lf[:2])), (lsum, lf)
+    assert_grads_close(acc, gf)
+
+
+def test_gather_matches_torch_sparse(data):
+    from scarches_amd import _lib
+    lib = _lib.load()
+    indptr, indices, vals = data["csr"]
+    rows = data["rows"]
+    x = torch.empty(B, G, device="cuda")
+    sf = torch.empty(B, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.sca_csr_gather_rows(indptr.data_ptr(), indices.data_ptr(), vals.data_ptr(), rows.data_ptr(), B, G, 1,
+                                       x.data_ptr(), G, sf.data_ptr(), st), "gather")
+    n = indptr.numel() - 1
+    dense = torch.sparse_csr_tensor(indptr, indices.to(torch.int64), vals, size=(n, G)).to_dense()[rows]
+    torch.cuda.synchronize()
+    assert torch.equal(x, torch.log1p(dense))                     # bit-exact: same log1pf on the same floats
+    assert float((sf - dense.sum(1)).abs().max()) <= 1e-6 * float(dense.sum(1).max())
+
+
+def _mmd_torch64(z, cond, n_cond, beta):
+    """models/trvae/losses.py:231-270 as written there (condition partition, pairwise mmd_loss_calc), fp64."""
+    alphas = torch.tensor([1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1, 5, 10, 15, 20, 25, 30, 35, 100, 1e3, 1e4, 1e5, 1e6],
+                          dtype=torch.float32, device=z.device).double()
+    bet = 1.0 / (2.0 * alphas)
+
+    def kern(x, y):
+        d2 = torch.cdist(x, y).pow(2)
+        return torch.exp(-bet.view(-1, 1, 1) * d2.unsqueeze(0)).sum(0)
+
+    parts = [z[cond == c] for c in range(n_cond)]
+    loss = z.new_zeros(())
+    for i in range(n_cond):
+        if parts[i].shape[0] < 1:
+            continue
+        for j in range(i):
+            if parts[j].shape[0] < 1:
+                continue
+            s, t = parts[i], parts[j]
+            loss = loss + kern(s, s).mean() + kern(t, t).mean() - 2 * kern(s, t).mean()
+    return beta * loss
+
+
+def test_mmd_full_size_against_torch_fp64():
+    from scarches_amd import _lib
+    lib = _lib.load()
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(11)
+    z = torch.randn(B, Z, device="cuda", generator=gen)
+    cond = torch.sort(torch.randint(0, C, (B,), device="cuda", generator=gen))[0].to(torch.int32)
+    z64 = z.double().requires_grad_(True)
+    ref = _mmd_torch64(z64, cond, C, 1.0)
+    ref.backward()
+    ns, npart = lib.sca_mmd_num_slabs(B, Z), lib.sca_mmd_num_partials(B, Z)
+    Wt = torch.empty(C * C, device="cuda")
+    part = torch.zeros(npart, dtype=torch.float64, device="cuda")
+    slabs = torch.full((ns, B, Z), float("nan"), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.sca_mmd_fwd_bwd(z.data_ptr(), Z, cond.data_ptr(), B, Z, C, -1, 1.0, Wt.data_ptr(), None,
+                                   part.data_ptr(), slabs.data_ptr(), B * Z, st), "mmd")
+    torch.cuda.synchronize()
+    val, grad = part.sum().item(), slabs.sum(0).double()
+    # value: rel 1e-5 of the sum of |block means| (the loss itself is a cancelling sum of C(C-1)/2 * 3 terms of O(10))
+    assert abs(val - ref.item()) <= 1e-5 * abs(ref.item()) + 2e-5, (val, ref.item())
+    err = float((grad - z64.grad).abs().max())
+    assert err <= 5e-5 * float(z64.grad.abs().max()), err
