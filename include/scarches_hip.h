@@ -259,6 +259,20 @@ int sca_class_moments_finish(const double* cnt, const double* sum, const double*
                              const float* prev_mean, const float* prev_cov, const uint8_t* update, float* mean,
                              float* cov, void* stream);
 
+/* ---- weighted kNN label transfer in the latent space (scarches/utils/knn.py:10-139) --------------------------
+ * sca_knn_topk replaces KNeighborsTransformer(algorithm="brute", metric="euclidean").fit(ref).kneighbors(qry)
+ * (knn.py:28-41,102): dist [Nq][k] ascending euclidean distances, idx [Nq][k] reference indices.  pd2 / pidx are
+ * workspaces of sca_knn_num_chunks(Nr, Nq) * Nq * k floats / int32.  k <= sca_knn_max_k(), k <= Nr, D <= 64.
+ * sca_knn_vote replaces the weight computation and the query x label double loop (knn.py:104-135) for ONE label
+ * column: labels [Nr] int32 codes in sorted label order; pred [Nq] winning code (first in sorted order on ties),
+ * prob [Nq] its probability in fp64 (uncertainty = max(1 - prob, 0)). */
+int sca_knn_max_k(void);
+int sca_knn_num_chunks(int Nr, int Nq);
+int sca_knn_topk(const float* ref, int Nr, const float* qry, int Nq, int D, int k, float* pd2, int32_t* pidx,
+                 float* dist, int32_t* idx, void* stream);
+int sca_knn_vote(const float* dist, const int32_t* idx, int Nq, int k, const int32_t* labels, int32_t* pred,
+                 double* prob, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

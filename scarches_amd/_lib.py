@@ -92,6 +92,10 @@ SIGNATURES = {
     "sca_mid_max_width": [],
     "sca_mid_fwd": [P, P],
     "sca_mid_bwd": [P, P],
+    "sca_knn_max_k": [],
+    "sca_knn_num_chunks": [I, I],
+    "sca_knn_topk": [P, I, P, I, I, I, P, P, P, P, P],
+    "sca_knn_vote": [P, P, I, I, P, P, P, P],
     "sca_grad_tail_max_jobs": [],
     "sca_grad_tail": [P, I, P],
     "sca_bn_fwd": [P, I, I, P, P, P, P, I, I, F, F, P, U64, U32, P, P, P, P, P],
