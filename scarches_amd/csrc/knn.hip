@@ -26,9 +26,13 @@ __device__ __forceinline__ void knn_insert(float* ld2, int* lid, int k, float d2
     lid[wslot * KNN_T + t] = id;
     float w = -1.f;
     int ws = 0;
-    for (int s = 0; s < k; ++s) {
-        const float v = ld2[s * KNN_T + t];
-        if (v > w) { w = v; ws = s; }
+    for (int s0 = 0; s0 < k; s0 += 8) {          // eight independent LDS reads in flight, then the compares
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = s0 + u < k ? ld2[(s0 + u) * KNN_T + t] : -1.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (v[u] > w) { w = v[u]; ws = s0 + u; }
     }
     worst = w;
     wslot = ws;
