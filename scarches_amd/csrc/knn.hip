@@ -5,21 +5,20 @@
 //     prediction = argmax_label P_i (first label in sorted order on ties), uncertainty = max(1 - P_i(pred), 0)
 // evaluated there in a Python double loop over queries x label columns.
 //
-// Top-k: one thread per query keeps its current k best (squared distance, index) as an UNSORTED list in LDS (slot-major
-// [k][threads]: conflict-free) together with the list's maximum; reference points stream through LDS in tiles and are
-// read as broadcasts, so the inner loop is D FMAs + one compare per pair and an insertion (replace the maximum, rescan
-// k slots) happens only ~k ln(N/k) times per query.  The reference set is split over blockIdx.y so that small query
-// sets still fill the chip; a second kernel merges the partial lists and sorts them ascending.
-// Algorithmic work per query: 3 D Nr flop, 4 D Nr bytes of reference read from L2/LDS (HBM: once per workgroup row).
+// Top-k: see knn_scan_kernel (a wave per group of queries, a lane per reference point, the k best of a query one per
+// lane in registers).  The reference set is split over blockIdx.y so that small query sets still fill the chip; a
+// second kernel merges the partial lists and sorts them ascending.
+// Algorithmic work per query: 3 D Nr flop; the reference is read from HBM/L2 once per 32 queries.
 #include "common.h"
 
 namespace {
 
-constexpr int KNN_T = 128;       // queries (threads) per workgroup
+constexpr int KNN_T = 128;       // queries (threads) per workgroup of the merge / vote kernels
 constexpr int KNN_RT = 256;      // reference points per LDS tile
-constexpr int KNN_KMAX = 64;
+constexpr int KNN_KMAX = 64;     // one list slot per lane
+constexpr int KNN_QWG = 32;      // queries per workgroup of the scan kernel at D <= 12 (4 waves x 8)
 
-// replace the list maximum by (d2, id) and find the new maximum
+// replace the list maximum by (d2, id) and find the new maximum (merge kernel: one thread per query, list in LDS)
 __device__ __forceinline__ void knn_insert(float* ld2, int* lid, int k, float d2, int id, float& worst, int& wslot) {
     const int t = threadIdx.x;
     ld2[wslot * KNN_T + t] = d2;
@@ -38,58 +37,86 @@ __device__ __forceinline__ void knn_insert(float* ld2, int* lid, int k, float d2
     wslot = ws;
 }
 
-template <int DMAX>
-__global__ __launch_bounds__(KNN_T) void knn_scan_kernel(const float* __restrict__ ref, int Nr,
-                                                         const float* __restrict__ qry, int Nq, int D, int k, int chunk,
-                                                         float* __restrict__ pd2, int32_t* __restrict__ pidx) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* ld2 = lds;                                   // [k][KNN_T]
-    int* lid = reinterpret_cast<int*>(lds + k * KNN_T); // [k][KNN_T]
-    float* tile = lds + 2 * k * KNN_T;                  // [KNN_RT][DMAX]
-    const int t = threadIdx.x;
-    const int qi = blockIdx.x * KNN_T + t;
-    const bool act = qi < Nq;
-    float q[DMAX];
+__device__ __forceinline__ float knn_uniform(float v) {   // a wave-uniform value, held in a scalar register
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+// Scan: a WAVE owns QW queries (their coordinates are wave-uniform registers) and every lane one reference point of
+// the current 64-point sub-tile, so one LDS read of the point serves QW distance evaluations and nothing diverges.
+// The k best of a query live one per lane (k <= 64: lane l < k holds list slot l, in registers): a candidate below
+// the list maximum is found with one ballot per 64 points, taken lane by lane through a scalar loop, and inserted by
+// the lane that holds the maximum (ballot + one wave max) - O(k ln(N/k)) insertions per query, each ~30 instructions.
+template <int DMAX, int QW>
+__global__ __launch_bounds__(256) void knn_scan_kernel(const float* __restrict__ ref, int Nr,
+                                                       const float* __restrict__ qry, int Nq, int D, int k, int chunk,
+                                                       float* __restrict__ pd2, int32_t* __restrict__ pidx) {
+    constexpr int LDR = DMAX + 1;                       // odd pitch: lane l reads point l without bank conflicts
+    __shared__ float tile[KNN_RT * LDR];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int q0 = (blockIdx.x * 4 + w) * QW;
+    float q[QW][DMAX];
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) q[d] = (act && d < D) ? qry[(long long)qi * D + d] : 0.f;
-    for (int s = 0; s < k; ++s) {
-        ld2[s * KNN_T + t] = INFINITY;
-        lid[s * KNN_T + t] = -1;
+    for (int qi = 0; qi < QW; ++qi)
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d)
+        {   // (kept in vector registers on purpose: 8 x 12 coordinates do not fit the scalar register file)
+            q[qi][d] = (q0 + qi < Nq && d < D) ? qry[(long long)(q0 + qi) * D + d] : 0.f;
+            asm volatile("" : "+v"(q[qi][d]));
+        }
+    float ld2[QW], worst[QW];
+    int lid[QW];
+#pragma unroll
+    for (int qi = 0; qi < QW; ++qi) {
+        ld2[qi] = lane < k ? INFINITY : -1.f;           // lanes past k never hold the maximum
+        lid[qi] = -1;
+        worst[qi] = INFINITY;
     }
-    float worst = INFINITY;
-    int wslot = 0;
     const int r_lo = blockIdx.y * chunk, r_hi = min(Nr, r_lo + chunk);
     for (int r0 = r_lo; r0 < r_hi; r0 += KNN_RT) {
         const int nr = min(KNN_RT, r_hi - r0);
         __syncthreads();
-        for (int i = t; i < nr * DMAX; i += KNN_T) {
-            const int r = i / DMAX, d = i - r * DMAX;
-            tile[i] = d < D ? ref[(long long)(r0 + r) * D + d] : 0.f;
+        const float* src = ref + (long long)r0 * D;
+        for (int e = t; e < nr * D; e += 256) {
+            const int rr = e / D, d = e - rr * D;
+            tile[rr * LDR + d] = src[e];
         }
         __syncthreads();
-        if (act) {
-            for (int r = 0; r < nr; ++r) {
-                const float4* tr = reinterpret_cast<const float4*>(tile + r * DMAX);
+        for (int sub = 0; sub < nr; sub += 64) {
+            const int rl = sub + lane;
+            const bool valid = rl < nr;
+            const float* tr = tile + min(rl, nr - 1) * LDR;
+            float r[DMAX];
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) r[d] = d < D ? tr[d] : 0.f;
+#pragma unroll
+            for (int qi = 0; qi < QW; ++qi) {
                 float d2 = 0.f;
 #pragma unroll
-                for (int d4 = 0; d4 < DMAX / 4; ++d4) {
-                    const float4 v = tr[d4];
-                    const float a0 = q[4 * d4] - v.x, a1 = q[4 * d4 + 1] - v.y, a2 = q[4 * d4 + 2] - v.z,
-                                a3 = q[4 * d4 + 3] - v.w;
-                    d2 = fmaf(a0, a0, d2); d2 = fmaf(a1, a1, d2); d2 = fmaf(a2, a2, d2); d2 = fmaf(a3, a3, d2);
+                for (int d = 0; d < DMAX; ++d) {
+                    const float a = r[d] - q[qi][d];
+                    d2 = fmaf(a, a, d2);
                 }
-                if (d2 < worst) knn_insert(ld2, lid, k, d2, r0 + r, worst, wslot);
+                unsigned long long m = __ballot(valid && d2 < worst[qi]);
+                while (m) {
+                    const int l = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const float cd = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d2), l));
+                    if (cd < worst[qi]) {
+                        const int wl = __ffsll((long long)__ballot(ld2[qi] == worst[qi])) - 1;
+                        if (lane == wl) { ld2[qi] = cd; lid[qi] = r0 + sub + l; }
+                        worst[qi] = knn_uniform(wave_max(ld2[qi]));
+                    }
+                }
             }
         }
     }
-    if (act) {
-        float* od = pd2 + ((long long)blockIdx.y * Nq + qi) * k;
-        int32_t* oi = pidx + ((long long)blockIdx.y * Nq + qi) * k;
-        for (int s = 0; s < k; ++s) {
-            od[s] = ld2[s * KNN_T + t];
-            oi[s] = lid[s * KNN_T + t];
+#pragma unroll
+    for (int qi = 0; qi < QW; ++qi)
+        if (q0 + qi < Nq && lane < k) {
+            const long long o = ((long long)blockIdx.y * Nq + q0 + qi) * k + lane;
+            pd2[o] = ld2[qi];
+            pidx[o] = lid[qi];
         }
-    }
 }
 
 // k best of the `chunks` partial lists of each query, sorted ascending by (distance, index); distances leave as sqrt.
@@ -194,9 +221,9 @@ extern "C" int sca_knn_max_k(void) { return KNN_KMAX; }
 // Number of reference chunks (blockIdx.y) sca_knn_topk uses; the caller sizes the partial workspace
 //   pd2 / pidx : chunks * Nq * k floats / int32 each.
 extern "C" int sca_knn_num_chunks(int Nr, int Nq) {
-    const long long qblocks = (Nq + KNN_T - 1) / KNN_T;
+    const long long qblocks = (Nq + KNN_QWG - 1) / KNN_QWG;
     long long chunks = (1024 + qblocks - 1) / qblocks;
-    const long long maxc = (Nr + 4 * KNN_RT - 1) / (4 * KNN_RT);      // at least four tiles per chunk
+    const long long maxc = (Nr + 8191) / 8192;           // a chunk scans at least 8192 reference points
     if (chunks > maxc) chunks = maxc;
     if (chunks < 1) chunks = 1;
     return (int)chunks;
@@ -211,23 +238,19 @@ extern "C" int sca_knn_topk(const float* ref, int Nr, const float* qry, int Nq, 
     const int chunks = sca_knn_num_chunks(Nr, Nq);
     int chunk = (Nr + chunks - 1) / chunks;
     chunk = ((chunk + KNN_RT - 1) / KNN_RT) * KNN_RT;
-    const dim3 grid((Nq + KNN_T - 1) / KNN_T, (Nr + chunk - 1) / chunk);
-    const int dmax = D <= 12 ? 12 : (D <= 16 ? 16 : (D <= 32 ? 32 : 64));
-    const size_t shm = sizeof(float) * ((size_t)2 * k * KNN_T + (size_t)KNN_RT * dmax);
-#define KNN_SCAN(DM)                                                                                                \
-    do {                                                                                                            \
-        hipFuncSetAttribute((const void*)knn_scan_kernel<DM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm); \
-        hipLaunchKernelGGL((knn_scan_kernel<DM>), grid, dim3(KNN_T), shm, st, ref, Nr, qry, Nq, D, k, chunk, pd2,   \
-                           pidx);                                                                                   \
-    } while (0)
-    if (dmax == 12) KNN_SCAN(12);
-    else if (dmax == 16) KNN_SCAN(16);
-    else if (dmax == 32) KNN_SCAN(32);
-    else KNN_SCAN(64);
+    const int ny = (Nr + chunk - 1) / chunk;
+#define KNN_SCAN(DM, QW)                                                                                            \
+    hipLaunchKernelGGL((knn_scan_kernel<DM, QW>), dim3((Nq + 4 * QW - 1) / (4 * QW), ny), dim3(256), 0, st, ref, Nr, \
+                       qry, Nq, D, k, chunk, pd2, pidx)
+    if (D <= 12) KNN_SCAN(12, 8);
+    else if (D <= 16) KNN_SCAN(16, 6);
+    else if (D <= 32) KNN_SCAN(32, 3);
+    else KNN_SCAN(64, 1);
 #undef KNN_SCAN
     const size_t shm2 = sizeof(float) * (size_t)2 * k * KNN_T;
     hipFuncSetAttribute((const void*)knn_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
-    hipLaunchKernelGGL(knn_merge_kernel, dim3(grid.x), dim3(KNN_T), shm2, st, pd2, pidx, Nq, k, (int)grid.y, dist, idx);
+    hipLaunchKernelGGL(knn_merge_kernel, dim3((Nq + KNN_T - 1) / KNN_T), dim3(KNN_T), shm2, st, pd2, pidx, Nq, k, ny,
+                       dist, idx);
     SCA_CHECK_LAUNCH();
     return 0;
 }
