@@ -184,3 +184,44 @@ def test_mmd_full_size_against_torch_fp64():
     assert abs(val - ref.item()) <= 1e-5 * abs(ref.item()) + 2e-5, (val, ref.item())
     err = float((grad - z64.grad).abs().max())
     assert err <= 5e-5 * float(z64.grad.abs().max()), err
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(Gx=333, Cx=3, Hx=[100, 37], Zx=7, Bx=77, recon="nb", use_ln=True, dr=0.1),
+    dict(Gx=512, Cx=5, Hx=[256, 128, 64], Zx=10, Bx=1000, recon="nb", use_ln=True, dr=0.05),      # wide (NS=4) path
+    dict(Gx=200, Cx=2, Hx=[64], Zx=3, Bx=33, recon="nb", use_ln=False, dr=0.0),                    # no norm, one layer
+    dict(Gx=200, Cx=2, Hx=[64, 32], Zx=5, Bx=130, recon="mse", use_ln=True, dr=0.0),               # MSE head
+    dict(Gx=1001, Cx=4, Hx=[128, 128, 128, 128], Zx=16, Bx=4097, recon="nb", use_ln=True, dr=0.2),
+])
+def test_fused_vs_unfused_odd_shapes(cfg):
+    """The fused middle kernels against the one-launch-per-layer path on ragged sizes: widths that are not multiples
+    of 4 (scalar load / store paths), wide layers, a single hidden layer, no LayerNorm, batch not a multiple of 32."""
+    from bench import build_trvae_params
+    from scarches_amd.engine import CVAEEngine
+    from scarches_amd.synth import make_synthetic_csr
+    Gx, Cx, Hx, Zx, Bx = cfg["Gx"], cfg["Cx"], cfg["Hx"], cfg["Zx"], cfg["Bx"]
+    dev = torch.device("cuda", 0)
+    indptr, indices, vals, cond_all, _ = make_synthetic_csr(6000, Gx, Cx, dev, seed=3)
+    rows = torch.arange(Bx, device=dev) * 1 % 6000
+    order = torch.argsort(cond_all[rows], stable=True)
+    rows = rows[order].contiguous()
+    cond = cond_all[rows].to(torch.int32).contiguous()
+    eps = torch.randn(Bx, Zx, device=dev)
+    engs = []
+    for fused in (True, False):
+        spec = dict(G=Gx, C=Cx, H=Hx, Z=Zx, recon=cfg["recon"], use_bn=False, use_ln=cfg["use_ln"], use_mmd=True,
+                    mmd_on="z", boundary=None, beta=1.0, dr_rate=cfg["dr"], seed=11, fused_mid=fused)
+        P = build_trvae_params(Gx, Cx, Hx, Zx)
+        if cfg["recon"] == "mse":      # the reference names the MSE head recon_decoder and has no dispersion
+            P = type(P)((k.replace("mean_decoder", "recon_decoder"), v) for k, v in P.items() if k != "theta")
+        e = CVAEEngine(spec, P, dev)
+        e.bind_csr(indptr, indices, vals)
+        e.begin_step(alpha_kl=0.3, lr=1e-3)
+        e.forward_backward(rows, cond, Bx, eps=eps)
+        engs.append(e)
+    torch.cuda.synchronize()
+    a, b = engs
+    assert a.use_fused_mid and not b.use_fused_mid
+    la, lb = a.losses.cpu().numpy(), b.losses.cpu().numpy()
+    assert np.all(np.isfinite(la)) and np.all(np.abs(la[:3] - lb[:3]) <= 1e-5 * np.abs(lb[:3]) + 1e-7), (la, lb)
+    assert_grads_close(grads(a), grads(b))
