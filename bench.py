@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--launch", choices=["auto", "plan", "graph", "eager"], default="auto",
-                    help="recorded launch plan, HIP-graph replay, eager launches, or auto (graph for B <= 2048, plan above)")
+                    help="recorded launch plan, HIP-graph replay, eager launches, or auto (graph for B <= 4096, plan above)")
     return ap.parse_args()
 
 

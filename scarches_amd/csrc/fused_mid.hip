@@ -188,7 +188,15 @@ __device__ __forceinline__ void load_tile(float* __restrict__ dst, int ld, const
             if (k < width && r0 + r < B) {
                 const float* p = src + (long long)(r0 + r) * width + k;
                 v = *reinterpret_cast<const float4*>(p);
-                for (int q = 1; q < S; ++q) {
+                int q = 1;
+                for (; q + 3 < S; q += 4) {                 // four slab loads in flight
+                    float4 u[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) u[i] = *reinterpret_cast<const float4*>(p + (q + i) * stride);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { v.x += u[i].x; v.y += u[i].y; v.z += u[i].z; v.w += u[i].w; }
+                }
+                for (; q < S; ++q) {
                     const float4 u = *reinterpret_cast<const float4*>(p + q * stride);
                     v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
                 }

@@ -1229,13 +1229,13 @@ class CVAEEngine:
         buffers, so the launch sequence of a given batch size never changes.  It is recorded once and then either
           * "plan" : re-issued from the recorded (function, arguments) list - no Python work per launch besides the
                      ctypes call itself, launches stay in the hand-ordered main-first sequence;
-                     "auto" for B > 2048 (the HIP-graph executor re-orders independent branches - it starts the MMD
-                     beside the likelihood kernel instead of beside the small decoder kernels: 0.52 vs 0.49 ms);
+                     "auto" for B > 4096 (the HIP-graph executor re-orders independent branches - it starts the MMD
+                     beside the likelihood kernel instead of beside the output GEMM: 0.84 vs 0.77 ms at B=8192);
           * True   : replayed as HIP graphs (one graph launch per step; best when launch-bound: 0.27 ms at B=128
-                     against 0.37 ms eager) - "auto" for B <= 2048;
+                     against 0.37 ms eager) - "auto" for B <= 4096 (0.46 ms at B=4096, where the plan is bimodal);
           * False  : launched eagerly through the normal Python path."""
         if use_graph == "auto":
-            use_graph = True if B <= 2048 else "plan"
+            use_graph = True if B <= 4096 else "plan"
         if use_graph is False:
             self.begin_step(alpha_kl, lr, eps, clip)
             self.forward_backward(row_ids, cond, B)

@@ -7,6 +7,22 @@ from scarches_amd import _lib
 from scarches_amd.engine import CVAEEngine
 from scarches_amd.synth import make_synthetic_csr
 
+def phases(L, rf, st, tag):
+    import ctypes
+    try:
+        fn = L.sca_mid_debug
+    except AttributeError:
+        return
+    buf = (ctypes.c_longlong * 64)()
+    L.sca_mid_fwd(rf, st); torch.cuda.synchronize()
+    fn(buf)
+    t = [buf[i] for i in range(16)]
+    names = ["first-layer epilogue", "enc1 gemm", "enc1 epilogue", "heads gemm", "latent", "dec0 gemm", "dec0 epilogue",
+             "dec1 gemm", "dec1 epilogue"]
+    marks = [t[15], t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8]]
+    print(tag, "fwd phases (us):", {n: round((marks[i + 1] - marks[i]) / 100.0, 2) for i, n in enumerate(names)},
+          "total", round((marks[-1] - marks[0]) / 100.0, 2), flush=True)
+
 dev = torch.device("cuda", 0)
 G, C, Z, H = 2000, 20, 10, [128, 128]
 indptr, indices, data, cond_all, _ = make_synthetic_csr(50_000, G, C, dev, seed=1000)
@@ -36,15 +52,5 @@ for B in (128, 4096, 16384):
             e1.record()
             torch.cuda.synchronize()
             print(f"B={B:6d} p={p:.2f} mid_{name}: {e0.elapsed_time(e1) / 20 * 1e3:8.1f} us", flush=True)
+        phases(L, rf, st, f"B={B} p={p}")
 
-# debug build only: phase timestamps of workgroup 0 (100 MHz wall clock)
-import ctypes
-try:
-    fn = L.sca_mid_debug
-    buf = (ctypes.c_longlong * 64)()
-    L.sca_mid_fwd(rf, st); torch.cuda.synchronize()
-    fn(buf)
-    t = [buf[i] for i in range(10)]
-    print("fwd phases (us since start):", [round((x - t[0]) / 100.0, 2) for x in t])
-except AttributeError:
-    pass
