@@ -444,10 +444,13 @@ class CVAEEngine:
         _lib.check(self.lib.sca_fill_zero(t.data_ptr(), t.numel() * t.element_size(), st), "fill_zero")
 
     def _gemm(self, am, bm, A, lda, Bm, ldb, M, N, K, st, out=None, ldc=None, bias=None, force_s1=False,
-              slab_key="slab"):
-        """Launch one GEMM; returns (ptr, S, slab_stride).  S == 1 with `out` writes the final tensor directly."""
+              slab_key="slab", max_split=None):
+        """Launch one GEMM; returns (ptr, S, slab_stride).  S == 1 with `out` writes the final tensor directly.
+        `max_split` caps the split-K count (the fused middle kernels sum the slabs serially per 32-row tile)."""
         L = self.lib
         S = 1 if force_s1 else L.sca_gemm_splitk_heuristic(M, N, K)
+        if max_split is not None:
+            S = min(S, max_split)
         rec = getattr(self, "record_gemms", None)
         if S == 1 and out is not None:
             args = (am, bm, A, lda, Bm, ldb, out, ldc or N, M, N, K, 1, 0, bias)
@@ -647,7 +650,7 @@ class CVAEEngine:
         a = ws["x"].data_ptr()
         if fused:       # first layer: GEMM only, its epilogue runs inside mid_fwd
             ly = self.enc[0]
-            pre0 = self._gemm(0, 0, a, ly.n_in, P[ly.w].data_ptr(), ly.n_in, B, ly.n_out, ly.n_in, st)
+            pre0 = self._gemm(0, 0, a, ly.n_in, P[ly.w].data_ptr(), ly.n_in, B, ly.n_out, ly.n_in, st, max_split=8)
             self._ev_pro = self._flush()
             return self._fused_path(row_ids, cond_p, B, train, compute_grad, eps, masks, accumulate_logs, p_drop, st,
                                     pre0)
@@ -1003,7 +1006,7 @@ class CVAEEngine:
             if T[self.out_w]:
                 self._grad_gemm(1, 1, dl, G, h_last, Hd, G, Hd, B, sa, Gd[self.out_w])
         self._defer(recon_side)
-        sp, S, stride = self._gemm(0, 1, dl, G, P[self.out_w].data_ptr(), Hd, B, Hd, G, st)
+        sp, S, stride = self._gemm(0, 1, dl, G, P[self.out_w].data_ptr(), Hd, B, Hd, G, st, max_split=8)
         if do_mmd:
             self._wait(ev_side)
         _lib.check(L.sca_mid_bwd(self._mid_args(B, cond_p, p_drop, eps, masks, sp, S, stride,
