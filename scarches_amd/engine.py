@@ -64,6 +64,7 @@ class CVAEEngine:
 
     def __init__(self, spec: dict, named_params: "OrderedDict[str, torch.Tensor]", device):
         self._rec = None
+        self._mid_max_split = None      # optional split-K cap of the two GEMMs whose slabs the fused kernels sum
         self.lib = _RecordingLib(_lib.load(), self)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -650,7 +651,7 @@ class CVAEEngine:
         a = ws["x"].data_ptr()
         if fused:       # first layer: GEMM only, its epilogue runs inside mid_fwd
             ly = self.enc[0]
-            pre0 = self._gemm(0, 0, a, ly.n_in, P[ly.w].data_ptr(), ly.n_in, B, ly.n_out, ly.n_in, st, max_split=8)
+            pre0 = self._gemm(0, 0, a, ly.n_in, P[ly.w].data_ptr(), ly.n_in, B, ly.n_out, ly.n_in, st, max_split=self._mid_max_split)
             self._ev_pro = self._flush()
             return self._fused_path(row_ids, cond_p, B, train, compute_grad, eps, masks, accumulate_logs, p_drop, st,
                                     pre0)
@@ -1006,7 +1007,7 @@ class CVAEEngine:
             if T[self.out_w]:
                 self._grad_gemm(1, 1, dl, G, h_last, Hd, G, Hd, B, sa, Gd[self.out_w])
         self._defer(recon_side)
-        sp, S, stride = self._gemm(0, 1, dl, G, P[self.out_w].data_ptr(), Hd, B, Hd, G, st, max_split=8)
+        sp, S, stride = self._gemm(0, 1, dl, G, P[self.out_w].data_ptr(), Hd, B, Hd, G, st, max_split=self._mid_max_split)
         if do_mmd:
             self._wait(ev_side)
         _lib.check(L.sca_mid_bwd(self._mid_args(B, cond_p, p_drop, eps, masks, sp, S, stride,
