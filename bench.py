@@ -119,6 +119,65 @@ def cpu_baseline(P, spec, csr_host, cond_host, B, budget_s=12.0):
                        f"{dt:.1f} s on {threads} torch threads")
 
 
+def hbm_kernel_rates(eng, B, G, nnz_per_cell, launch, reps=20):
+    """Achieved HBM GB/s of the two HBM-side kernels of the step (north_star: gather and likelihood against the
+    MI355X peak), measured live: the kernel's own launch of the recorded step is re-issued between HIP events on the
+    launch stream.  Algorithmic bytes per cell (DESIGN.md section 3): gather reads 8*nnz + 24 and writes 4*G + 4;
+    the likelihood reads 4*G (logits) + 8*nnz (counts + columns) and writes 4*G (d-logits in place)."""
+    plans = getattr(eng, "_plans", {})
+    plan = next((g["fwd"] for k, g in plans.items() if k[0] == B and isinstance(g["fwd"], list)), None)
+    if plan is None:        # the timed run used a HIP graph / eager launches: record a plan of the same step once
+        eng.train_step(torch.zeros(B, dtype=torch.int64, device=eng.device),
+                       torch.zeros(B, dtype=torch.int32, device=eng.device), B, 0.5, 1e-3, use_graph="plan")
+        plan = next(g["fwd"] for k, g in eng._plans.items() if k[0] == B and isinstance(g["fwd"], list))
+    torch.cuda.synchronize()
+    st = torch.cuda.current_stream(eng.device)
+    peak = 8000.0
+    res = {}
+
+    def find(name):
+        return next(((fn, args) for fn, args, _ in plan if getattr(fn, "__name__", "") == name), None)
+
+    hit = find("sca_csr_gather_rows")
+    if hit:
+        fn, args = hit
+        for _ in range(3):
+            fn(*args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            fn(*args)
+        e1.record(st)
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        byt = B * (8.0 * nnz_per_cell + 24 + 4.0 * G + 4)
+        res["csr_gather_kernel"] = {"bound": "hbm", "avg_launch_us": us, "bytes_per_launch": byt,
+                                    "achieved": byt / us / 1e3, "peak": peak, "unit": "GB/s",
+                                    "frac": byt / us / 1e3 / peak}
+    hit = find("sca_recon_rows")
+    if hit:
+        fn, args = hit
+        logits = eng.ws["logits"]
+        keep = logits.clone()           # the kernel overwrites the logits with d-logits: restore before every launch
+        tot = 0.0
+        for i in range(3 + reps):
+            logits.copy_(keep)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            fn(*args)
+            e1.record(st)
+            torch.cuda.synchronize()
+            if i >= 3:
+                tot += e0.elapsed_time(e1)
+        us = tot / reps * 1e3
+        byt = B * (8.0 * G + 8.0 * nnz_per_cell)
+        res["recon_rows_kernel"] = {"bound": "hbm", "avg_launch_us": us, "bytes_per_launch": byt,
+                                    "achieved": byt / us / 1e3, "peak": peak, "unit": "GB/s",
+                                    "frac": byt / us / 1e3 / peak,
+                                    "note": "alone on the chip; inside the step it shares the CUs with the MMD kernel"}
+    return res
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -230,6 +289,7 @@ def main():
                            "launches_per_step": len(calls), "flop_per_step": flops,
                            "avg_launch_us": t_gemm / len(calls) * 1e6,
                            "gemm_share_of_step": t_gemm / (dt / a.steps)}
+        out["hbm_kernels"] = hbm_kernel_rates(eng, B, G, data.numel() / n_local, a.launch)
         if not a.no_sweep and world == 1:
             sweep = {}
             for Bx in (128, 1024, 4096, 16384):

@@ -13,6 +13,7 @@
 // quarter-rate v_exp_f32; see rbf19 and mmd_small_kernel for how the exp count per ordered pair is cut from 19 to ~4.5.
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -148,6 +149,31 @@ __device__ __forceinline__ void rbf_terms(int a, const float (&d2)[U], v2f (&KK)
         }
     }
 }
+// The nine middle bandwidths (alpha = 0.1 ... 35) with SIX exps: 1/(2 alpha) of alpha = 20 -> 10 -> 5 and of
+// alpha = 30 -> 15 double at every step, so those kernels are successive squares of exp(-d2/40) and exp(-d2/60)
+// (the argument rounding of the fp32 product beta*d2 dominates the error of either form).
+template <int U>
+__device__ __forceinline__ void rbf_mid(const float (&d2)[U], v2f (&KK)[U]) {
+    constexpr float LOG2E = 1.4426950408889634f;
+    rbf_terms<U>(5, d2, KK);     // alpha 0.1
+    rbf_terms<U>(6, d2, KK);     // alpha 1
+    rbf_terms<U>(11, d2, KK);    // alpha 25
+    rbf_terms<U>(13, d2, KK);    // alpha 35
+    constexpr float c20 = -(mmd_beta(10) * LOG2E), c30 = -(mmd_beta(12) * LOG2E);
+    const v2f b20 = {1.0f, mmd_beta(10)}, b10 = {1.0f, mmd_beta(8)}, b5 = {1.0f, mmd_beta(7)};
+    const v2f b30 = {1.0f, mmd_beta(12)}, b15 = {1.0f, mmd_beta(9)};
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const float e20 = __builtin_amdgcn_exp2f(c20 * d2[u]), e30 = __builtin_amdgcn_exp2f(c30 * d2[u]);
+        const float e10 = e20 * e20, e15 = e30 * e30;
+        const float e5 = e10 * e10;
+        KK[u] = pk_fma(v2f{e20, e20}, b20, KK[u]);
+        KK[u] = pk_fma(v2f{e30, e30}, b30, KK[u]);
+        KK[u] = pk_fma(v2f{e10, e10}, b10, KK[u]);
+        KK[u] = pk_fma(v2f{e15, e15}, b15, KK[u]);
+        KK[u] = pk_fma(v2f{e5, e5}, b5, KK[u]);
+    }
+}
 // U independent pairs per call: the per-pair chains (exp -> accumulate, Horner) are latency-bound on their own
 template <int U>
 __device__ __forceinline__ void rbf19(const float (&d2)[U], v2f (&KK)[U]) {
@@ -158,8 +184,7 @@ __device__ __forceinline__ void rbf19(const float (&d2)[U], v2f (&KK)[U]) {
         near |= d2[u] < 1.75f;
         far |= d2[u] > MMD_POLY_MAX_D2;
     }
-#pragma unroll
-    for (int a = 5; a < MMD_WIDE0; ++a) rbf_terms<U>(a, d2, KK);
+    rbf_mid<U>(d2, KK);
     // (the opaque copies pin the rarely needed exps inside their branches: hipcc otherwise speculates them)
     if (__ballot(near) != 0ull) {
         float dn[U];
@@ -456,6 +481,8 @@ __global__ __launch_bounds__(256) void mmd_generic_kernel(const float* __restric
 static int mmd_small_jr(int B) {
     const long long nb = (B + MMD_T - 1) / MMD_T, nbc = (B + MMD_TC - 1) / MMD_TC;
     long long jr = ((nb + 3) / 4) * nbc / 2 / 1024;
+    static const int jr_env = [] { const char* v = getenv("SCA_MMD_JR"); return v ? atoi(v) : 0; }();
+    if (jr_env > 0) jr = jr_env;
     if (jr < 1) jr = 1;
     if (jr > 32) jr = 32;
     return (int)jr;

@@ -111,7 +111,7 @@ __device__ __forceinline__ bool nb_gamma_fast_ok(float x, float th) {
 constexpr int QMAX = 1024;     // LDS queue of heavy entries per row (overflow is handled inline)
 
 template <int T, int EPT, bool ZINB>
-__global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
+__global__ __launch_bounds__(T, 4) void recon_rows_kernel(const ReconArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* tx = lds;              // [G] per-row extras of t = mu dll/dmu at nnz (cleared by the owner when read)
     float* dx = lds + a.G;        // [G] theta-gradient extras, accumulated over the rows of a condition run
@@ -132,9 +132,31 @@ __global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
     const int b0 = blockIdx.x * a.rows_per_block, b1 = min(a.B, b0 + a.rows_per_block);
     const float invB = 1.0f / (float)a.B;
     int par = 0;                  // reduction scratch parity: alternating buffers need ONE barrier per reduction
+    // Row scalars (condition, size factor, CSR extent) of up to RS rows are fetched in one go: the row id -> indptr ->
+    // counts chain is paid once per RS rows instead of once per row
+    constexpr int RS = 64;
+    __shared__ long long s_ks[RS];
+    __shared__ int s_nn[RS], s_c[RS];
+    __shared__ float s_sf[RS];
+    float thr[EPT], lter[EPT];    // per-gene table values of this thread, reloaded when the condition changes
+    int ccur = -2;
     for (int b = b0; b < b1; ++b) {
-        const int c = a.cond ? a.cond[b] : 0;
-        const float s = a.sizefactor[b];
+        if (((b - b0) & (RS - 1)) == 0) {
+            __syncthreads();
+            if (t < RS && b + t < b1) {
+                const int bb = b + t;
+                const int64_t r = a.row_ids ? a.row_ids[bb] : (int64_t)bb;
+                const int64_t k0 = a.indptr[r];
+                s_ks[t] = k0;
+                s_nn[t] = (int)(a.indptr[r + 1] - k0);
+                s_c[t] = a.cond ? a.cond[bb] : 0;
+                s_sf[t] = a.sizefactor[bb];
+            }
+            __syncthreads();
+        }
+        const int c = s_c[(b - b0) & (RS - 1)];
+        const float s = s_sf[(b - b0) & (RS - 1)];
+        const int64_t ks = s_ks[(b - b0) & (RS - 1)], ke = ks + s_nn[(b - b0) & (RS - 1)];
         float* lrow = a.logits + (long long)b * a.ldl;
         float* prow = ZINB ? a.pi + (long long)b * a.ldl : nullptr;
         const float* tth = a.tab_theta + (long long)c * G;
@@ -150,9 +172,36 @@ __global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
             lg[j] = g < G ? lrow[g] + (coff ? coff[g] : 0.f) : -INFINITY;
             mx = fmaxf(mx, lg[j]);
         }
+        // the first stored count of this lane travels together with the logits (its two dependent reads overlap the
+        // softmax reduction below)
+        const bool has0 = ks + t < ke;
+        float x0 = 0.f, th0 = 1.f, lv0 = 0.f;
+        int g0 = 0;
+        if (has0) {
+            x0 = a.data[ks + t];
+            g0 = a.indices[ks + t];
+            th0 = tth[g0];
+            lv0 = lrow[g0] + (coff ? coff[g0] : 0.f);
+        }
+        if (c != ccur) {
+            ccur = c;
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) {
+                const int g = t + T * j;
+                thr[j] = g < G ? tth[g] : 1.f;
+                // ZINB keeps log(theta + eps); NB keeps 1 / (theta + eps) (its dense sweep needs no other table value)
+                if (ZINB) lter[j] = g < G ? tlt[g] : 0.f;
+                else lter[j] = __builtin_amdgcn_rcpf(thr[j] + NB_EPS);
+            }
+        }
+        // lg[j] <- exp(logit - thread max): the ONE exp of a gene; gamma = lg[j] * fgam once the row statistics are in
         float se = 0.f;
 #pragma unroll
-        for (int j = 0; j < EPT; ++j) se += (t + T * j < G) ? __expf(lg[j] - mx) : 0.f;
+        for (int j = 0; j < EPT; ++j) {
+            lg[j] = (t + T * j < G) ? __expf(lg[j] - mx) : 0.f;
+            se += lg[j];
+        }
+        const float mxt = mx;
         {
             float wm = wave_max(mx);
             se *= (mx == -INFINITY) ? 0.f : __expf(mx - wm);
@@ -169,29 +218,31 @@ __global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
             par ^= 1;
         }
         const float inv = 1.0f / se;
+        const float fgam = (mxt == -INFINITY) ? 0.f : __expf(mxt - mx) * inv, fmu = fgam * s;
 
         // ---- sparse phase: one lane per stored count of this row
         float ll = 0.f;
-        const int64_t r = a.row_ids ? a.row_ids[b] : (int64_t)b;
-        const int64_t ks = a.indptr[r], ke = a.indptr[r + 1];
-        for (int64_t k = ks + t; k < ke; k += T) {
-            const float x = a.data[k];
-            if (!(x > NB_EPS)) continue;
-            const int g = a.indices[k];
-            const float th = tth[g];
-            const float mu = __expf(lrow[g] + (coff ? coff[g] : 0.f) - mx) * inv * s;
+        auto stored = [&](int64_t k, float x, int g, float th, float lv) {
+            if (!(x > NB_EPS)) return;
+            const float mu = __expf(lv - mx) * inv * s;
             const float den = th + mu + NB_EPS;
             const float L = __logf(den), rr = __builtin_amdgcn_rcpf(den);
             float lgam = 0.f, dig = 0.f;
             if (nb_gamma_fast_ok(x, th)) {
+                // prod_k (theta+k) and sum_k 1/(theta+k) = num/den built without divisions (three full-rate ops per
+                // term + the factorial alongside; theta < 128 keeps 16 factors inside fp32 range): ONE rcp per count
                 const int n = min((int)x, 16);
-                float P = 1.f;
+                float num = 0.f, den = 1.f, fact = 1.f, f = th, fq = 1.f;
                 for (int q = 0; q < n; ++q) {
-                    const float f = th + (float)q;
-                    P *= f * __builtin_amdgcn_rcpf((float)(q + 1));
-                    dig += __builtin_amdgcn_rcpf(f);
+                    num = fmaf(num, f, den);
+                    den *= f;
+                    fact *= fq;
+                    f += 1.0f;
+                    fq += 1.0f;
                 }
-                lgam = __logf(P);
+                const float rden = __builtin_amdgcn_rcpf(den);
+                dig = num * rden;
+                lgam = -__logf(fact * rden);
             } else {
                 const int slot = atomicAdd(&qn, 1);
                 if (slot < QMAX) queue[slot] = (int)(k - ks);
@@ -215,6 +266,11 @@ __global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
             ll += ex_ll;
             tx[g] = ex_t;                 // joins t_g (and the row total T) in the dense sweep
             dx[g] += ex_th;
+        };
+        if (has0) stored(ks + t, x0, g0, th0, lv0);
+        for (int64_t k = ks + t + T; k < ke; k += T) {
+            const int g = a.indices[k];
+            stored(k, a.data[k], g, tth[g], lrow[g] + (coff ? coff[g] : 0.f));
         }
         __syncthreads();
         // ---- heavy entries (large / non-integer counts), compacted so the fp64 code runs on full lanes
@@ -240,15 +296,25 @@ __global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
             const int g = t + T * j;
             tj[j] = 0.f; pj[j] = 0.f;
             if (g < G) {
-                const float th = tth[g], lte = tlt[g];
-                const float gam = __expf(lg[j] - mx) * inv;
-                const float mu = gam * s;
+                const float th = thr[j];
+                const float gam = lg[j] * fgam, mu = lg[j] * fmu;
                 const float den = th + mu + NB_EPS;
-                const float L = __logf(den), rr = __builtin_amdgcn_rcpf(den);
-                const float base = th * (lte - L);
-                const float dbase_dth = lte - L + th * (__builtin_amdgcn_rcpf(th + NB_EPS) - rr);
+                const float rr = __builtin_amdgcn_rcpf(den);
                 float tv, dth;
-                if (ZINB) {
+                if (!ZINB) {
+                    // theta (log(theta+eps) - log(theta+mu+eps)) as ONE log of the ratio; with u = -theta/den:
+                    //   t = mu u,   theta d/dtheta = base + theta (theta/(theta+eps) + u)
+                    const float r1 = lter[j];
+                    const float base = -th * __logf(den * r1);
+                    const float u = -th * rr;
+                    ll += base;
+                    tv = mu * u;
+                    dth = fmaf(th, fmaf(th, r1, u), base);
+                } else {
+                    const float lte = lter[j];
+                    const float L = __logf(den);
+                    const float base = th * (lte - L);
+                    const float dbase_dth = lte - L + th * (__builtin_amdgcn_rcpf(th + NB_EPS) - rr);
                     const float pv = prow[g];
                     const float ptl = -pv + base;
                     const float sg = sigmoid_f(ptl);
@@ -257,10 +323,6 @@ __global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
                     dth = th * sg * dbase_dth;
                     pj[j] = (sigmoid_f(-pv) - sg) + px[g];
                     px[g] = 0.f;
-                } else {
-                    ll += base;
-                    tv = -mu * th * rr;
-                    dth = th * dbase_dth;
                 }
                 tv += tx[g];
                 tx[g] = 0.f;
@@ -298,7 +360,8 @@ __global__ __launch_bounds__(T) void recon_rows_kernel(const ReconArgs a) {
                 }
             }
             const bool last = (b + 1 == b1);
-            const int cn = last ? -1 : (a.cond ? a.cond[b + 1] : 0);
+            const int nxt = (b + 1 - b0) & (RS - 1);      // a refill of the row scalars also closes the run
+            const int cn = (last || nxt == 0) ? -1 : s_c[nxt];
             if (last || cn != c) {
                 float* dst = a.dthetaT + (long long)c * G;
 #pragma unroll

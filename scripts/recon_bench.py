@@ -12,7 +12,7 @@ indptr, indices, data, cond_all, _ = make_synthetic_csr(100_000, G, C, dev, seed
 print("max count", data.max().item(), "frac > 16:", (data > 16).float().mean().item(), flush=True)
 P = build_trvae_params(G, C, H, Z)
 gen = torch.Generator(device=dev); gen.manual_seed(1)
-for B in (4096, 16384):
+for B in (8192,):
     spec = dict(G=G, C=C, H=H, Z=Z, recon="nb", use_bn=False, use_ln=True, use_mmd=True, mmd_on="z", boundary=None,
                 beta=1.0, dr_rate=0.05, seed=2020)
     eng = CVAEEngine(spec, P, dev)
@@ -21,12 +21,12 @@ for B in (4096, 16384):
     eng.train_step(ids[0], cs[0], B, 0.5, 1e-3, use_graph="plan")
     torch.cuda.synchronize()
     plan = next(iter(eng._plans.values()))["fwd"]
-    for name in ("sca_recon_rows", "sca_csr_gather_dense"):
+    for name in ("sca_recon_rows", "sca_csr_gather_rows"):
         hits = [(fn, args) for fn, args, _ in plan if getattr(fn, "__name__", "") == name]
         if not hits:
             print("no", name, [getattr(f, "__name__", "?") for f, _, _ in plan][:40]); continue
         fn, args = hits[0]
-        variants = (1, 2, 4, 8, 16) if name == "sca_recon_rows" else (None,)
+        variants = (4, 8) if name == "sca_recon_rows" else (None,)
         for rpb in variants:
             a = list(args)
             if rpb is not None:
