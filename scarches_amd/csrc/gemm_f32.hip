@@ -16,11 +16,14 @@
 // (exact fp32: bit-identical to an fmaf chain in k order, so parity with the CPU reference is limited only
 // by summation order).  LDS tiles are k-major with a +4 pad: fragment reads are conflict-free ds_read_b32,
 // transposing stores of the k-contiguous operands are 2-way (free on ds_write_b32).  Global->LDS staging is
-// register-prefetched, the k loop runs on a three-stage LDS ring with double-buffered fragment registers (one barrier
-// per k-step; see gemm_body).
+// register-prefetched two k-steps ahead (two register sets), the k loop runs on a three-stage LDS ring with
+// double-buffered fragment registers and is branch-free in its steady state (one barrier per k-step; see gemm_body).
+// Measured and dropped: two accumulators per single-tile wave (even / odd MFMAs of a k-step) - slower, the
+// accumulator chain is not what bounds the loop.
 // Split-K (gridDim.z) writes per-split slabs; the consumer kernel sums them (deterministic, no atomics).
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -91,6 +94,28 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
     }
 }
 
+// Branch-free variant for tiles that are complete in k (every tile but possibly the last of a split): rows past
+// the operand's end are clamped to a valid row instead of being zero-filled - such rows only feed output rows /
+// columns that the epilogue never stores.  Needs 16-byte loads (VEC) and, for the k-major layout, R % 4 == 0.
+// Straight-line code lets the compiler wait for exactly the tile it is about to store (counted vmcnt) while the
+// next tile's loads stay in flight.
+template <int MODE, int W>
+__device__ __forceinline__ void load_tile_fast(const float* __restrict__ P, int ld, int R, int r0, int k0,
+                                               float4 (&reg)[W * BK / 16]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < W * BK / 16; ++i) {
+        const int idx = t + 256 * i;
+        if (MODE == 0) {
+            const int r = min(r0 + idx / (BK / 4), R - 1), k = k0 + 4 * (idx % (BK / 4));
+            reg[i] = *reinterpret_cast<const float4*>(P + (long long)r * ld + k);
+        } else {
+            const int k = k0 + idx / (16 * W), r = min(r0 + 4 * (idx % (16 * W)), R - 4);
+            reg[i] = *reinterpret_cast<const float4*>(P + (long long)k * ld + r);
+        }
+    }
+}
+
 template <int MODE, int W>
 __device__ __forceinline__ void store_tile(float* __restrict__ T, const float4 (&reg)[W * BK / 16]) {
     constexpr int LDT = 64 * W + 4;
@@ -136,27 +161,33 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int tile, int zs, f
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (kend - kbeg + BK - 1) / BK;
-    float4 ra[WM * BK / 16], rb[WN * BK / 16];
-    // LDS image: three A stages then three B stages.  Stage s holds k-tile kt with kt % 3 == s: while tile kt feeds
-    // the MFMAs, the fragments of tile kt+1 (complete since the previous barrier) are read into the second fragment
-    // register set BETWEEN those MFMAs, and tile kt+2 travels global -> registers -> stage (kt+2) % 3.  The LDS
-    // latency at k-step boundaries - a third of the loop with two stages - is hidden; one barrier per k-step still
+    // LDS image: three A stages then three B stages.  Stage s holds k-tile kt with kt % 3 == s.  In k-step kt
+    //   * the MFMAs consume the fragment registers of tile kt (set kt & 1),
+    //   * the fragments of tile kt+1 (in LDS since the previous barrier) are read into the other set BETWEEN them,
+    //   * tile kt+2, requested from global memory one k-step ago (register set kt & 1), is stored to stage (kt+2) % 3,
+    //   * tile kt+3 is requested into the other register set.
+    // A global load so has two k-steps (>= 1024 MFMA cycles of this wave alone) to land; one barrier per k-step
     // suffices (the stage written in step kt was last read in step kt-2).
+    float4 ra[2][WM * BK / 16], rb[2][WN * BK / 16];
     float* As = lds;
     float* Bs = lds + NSTAGE * ASZ;
     const int aoff = half * LDA + wm * (32 * WM) + l31, boff = half * LDB + wn * (32 * WN) + l31;
     float av[2][BK / 2][WM], bv[2][BK / 2][WN];
     if (nk > 0) {
-        load_tile<AMODE, VEC, WM>(a.A, a.lda, a.M, m0, kbeg, kend, ra);
-        load_tile<BMODE, VEC, WN>(a.B, a.ldb, a.N, n0, kbeg, kend, rb);
-        store_tile<AMODE, WM>(As, ra);
-        store_tile<BMODE, WN>(Bs, rb);
+        load_tile<AMODE, VEC, WM>(a.A, a.lda, a.M, m0, kbeg, kend, ra[0]);
+        load_tile<BMODE, VEC, WN>(a.B, a.ldb, a.N, n0, kbeg, kend, rb[0]);
+        store_tile<AMODE, WM>(As, ra[0]);
+        store_tile<BMODE, WN>(Bs, rb[0]);
     }
     if (nk > 1) {
-        load_tile<AMODE, VEC, WM>(a.A, a.lda, a.M, m0, kbeg + BK, kend, ra);
-        load_tile<BMODE, VEC, WN>(a.B, a.ldb, a.N, n0, kbeg + BK, kend, rb);
-        store_tile<AMODE, WM>(As + ASZ, ra);
-        store_tile<BMODE, WN>(Bs + BSZ, rb);
+        load_tile<AMODE, VEC, WM>(a.A, a.lda, a.M, m0, kbeg + BK, kend, ra[1]);
+        load_tile<BMODE, VEC, WN>(a.B, a.ldb, a.N, n0, kbeg + BK, kend, rb[1]);
+        store_tile<AMODE, WM>(As + ASZ, ra[1]);
+        store_tile<BMODE, WN>(Bs + BSZ, rb[1]);
+    }
+    if (nk > 2) {
+        load_tile<AMODE, VEC, WM>(a.A, a.lda, a.M, m0, kbeg + 2 * BK, kend, ra[0]);
+        load_tile<BMODE, VEC, WN>(a.B, a.ldb, a.N, n0, kbeg + 2 * BK, kend, rb[0]);
     }
     __syncthreads();
     if (nk > 0) {
@@ -168,13 +199,38 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int tile, int zs, f
             for (int j = 0; j < WN; ++j) bv[0][kk][j] = Bs[boff + (2 * kk) * LDB + 32 * j];
         }
     }
-    // one k-step: MFMAs on fragment set P, fragment reads of the next tile into set 1-P interleaved among them
+    // steady state: tiles kt+1 .. kt+3 exist and are complete in k; no branches between the barriers
+    auto kstep_fast = [&](auto PP, int kt) {
+        constexpr int P = decltype(PP)::value;
+        load_tile_fast<AMODE, WM>(a.A, a.lda, a.M, m0, kbeg + (kt + 3) * BK, ra[1 - P]);
+        load_tile_fast<BMODE, WN>(a.B, a.ldb, a.N, n0, kbeg + (kt + 3) * BK, rb[1 - P]);
+        const int s1 = (kt + 1) % NSTAGE;
+        const float* An = As + s1 * ASZ + aoff;
+        const float* Bn = Bs + s1 * BSZ + boff;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[P][kk][i], bv[P][kk][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < WM; ++i) av[1 - P][kk][i] = An[(2 * kk) * LDA + 32 * i];
+#pragma unroll
+            for (int j = 0; j < WN; ++j) bv[1 - P][kk][j] = Bn[(2 * kk) * LDB + 32 * j];
+        }
+        const int s2 = (kt + 2) % NSTAGE;
+        store_tile<AMODE, WM>(As + s2 * ASZ, ra[P]);
+        store_tile<BMODE, WN>(Bs + s2 * BSZ, rb[P]);
+        __syncthreads();
+    };
+    // general k-step (first / last steps of a split, partial tiles, operands without 16-byte loads)
     auto kstep = [&](auto PP, int kt) {
         constexpr int P = decltype(PP)::value;
-        const bool more2 = kt + 2 < nk, more1 = kt + 1 < nk;
-        if (more2) {
-            load_tile<AMODE, VEC, WM>(a.A, a.lda, a.M, m0, kbeg + (kt + 2) * BK, kend, ra);
-            load_tile<BMODE, VEC, WN>(a.B, a.ldb, a.N, n0, kbeg + (kt + 2) * BK, kend, rb);
+        const bool more3 = kt + 3 < nk, more2 = kt + 2 < nk, more1 = kt + 1 < nk;
+        if (more3) {
+            load_tile<AMODE, VEC, WM>(a.A, a.lda, a.M, m0, kbeg + (kt + 3) * BK, kend, ra[1 - P]);
+            load_tile<BMODE, VEC, WN>(a.B, a.ldb, a.N, n0, kbeg + (kt + 3) * BK, kend, rb[1 - P]);
         }
         const int s1 = (kt + 1) % NSTAGE;
         const float* An = As + s1 * ASZ + aoff;
@@ -195,12 +251,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int tile, int zs, f
         }
         if (more2) {
             const int s2 = (kt + 2) % NSTAGE;
-            store_tile<AMODE, WM>(As + s2 * ASZ, ra);
-            store_tile<BMODE, WN>(Bs + s2 * BSZ, rb);
+            store_tile<AMODE, WM>(As + s2 * ASZ, ra[P]);
+            store_tile<BMODE, WN>(Bs + s2 * BSZ, rb[P]);
         }
         __syncthreads();
     };
-    for (int kt = 0; kt < nk; kt += 2) {
+    // steps [0, nfast) run branch-free: tile kt+3 <= nk-2 is complete in k for every kt < nk-4
+    const bool fast_ok = VEC && (AMODE == 0 || (a.M & 3) == 0) && (BMODE == 0 || (a.N & 3) == 0) &&
+                         (AMODE == 1 || a.M >= 1) && (BMODE == 1 || a.N >= 1) && a.M >= 4 && a.N >= 4;
+    const int nfast = fast_ok ? max(0, nk - 4) & ~1 : 0;
+    int kt = 0;
+    for (; kt < nfast; kt += 2) {
+        kstep_fast(std::integral_constant<int, 0>{}, kt);
+        kstep_fast(std::integral_constant<int, 1>{}, kt + 1);
+    }
+    for (; kt < nk; kt += 2) {
         kstep(std::integral_constant<int, 0>{}, kt);
         if (kt + 1 < nk) kstep(std::integral_constant<int, 1>{}, kt + 1);
     }
@@ -289,8 +354,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }  // namespace
 
 // Tile + split-K plan (measured on MI355X, scripts/gemm_bench*.py): for the skinny shapes of this network
-// (one dimension = 128 or less) 64x64 tiles with the smallest power-of-two split that yields >= 512 workgroups are
-// fastest or tied; 128x128 tiles only pay once the 64x64 grid exceeds ~4096 tiles (large square-ish problems).
+// (one dimension = 128 or less) 64x64 tiles with the smallest power-of-two split that yields >= 1024 workgroups
+// (4 per CU, all resident at once: 76-90 VGPRs, 26 KB LDS) are fastest or tied - at B = 8192 the wide GEMMs take
+// 45-49 us there against 53-59 us at 512 workgroups; 128x128 tiles only pay once the 64x64 grid exceeds ~4096 tiles
+// (large square-ish problems).  SCA_GEMM_WG_TARGET overrides the workgroup target (tuning knob).
 struct GemmPlan { int wm, wn, S; };
 static GemmPlan plan_gemm(int M, int N, int K) {
     const int kt = (K + BK - 1) / BK;
@@ -301,7 +368,8 @@ static GemmPlan plan_gemm(int M, int N, int K) {
         p.wm = p.wn = 2;
         tiles = (long long)((M + 127) / 128) * ((N + 127) / 128);
     }
-    while (tiles * p.S < 512 && p.S < 64 && kt / (p.S * 2) >= 2) p.S *= 2;
+    static const int wg_target = [] { const char* v = getenv("SCA_GEMM_WG_TARGET"); return v ? atoi(v) : 1024; }();
+    while (tiles * p.S < wg_target && p.S < 64 && kt / (p.S * 2) >= 2) p.S *= 2;
     return p;
 }
 

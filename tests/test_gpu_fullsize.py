@@ -118,7 +118,10 @@ def test_batch_additivity_without_mmd(data):
         g = grads(e)
         acc = {k: w * v for k, v in g.items()} if acc is None else {k: acc[k] + w * g[k] for k in g}
     assert np.all(np.abs(lsum - lf[:2]) <= 1e-5 * np.abs(lf[:2])), (lsum, lf)
-    assert_grads_close(acc, gf)
+    # the pieces run their GEMMs with other split-K counts than the full batch: a pre-activation within rounding of 0
+    # (about one in 1e7 at these sizes) can land on the other side of the ReLU and move single gradient entries by one
+    # cell's contribution (observed 7.6e-5 of the tensor's max for one split choice, 0 for its neighbours)
+    assert_grads_close(acc, gf, rtol=3e-4)
 
 
 def test_gather_matches_torch_sparse(data):
