@@ -52,8 +52,8 @@ template <int K> struct MmdPoly {
 };
 
 // Condition counts -> weight table Wt[C][C] (workgroup 0); the other workgroups clear `zero_buf` (the gradient
-// accumulator of the small-D kernel).  Counting walks contiguous segments so that condition-sorted minibatches cost
-// one LDS atomic per run, not one per cell.
+// accumulator of the small-D kernel).  Counting looks at run boundaries so that condition-sorted minibatches cost
+// two LDS atomics per run, not one per cell.
 __global__ __launch_bounds__(256) void mmd_prepare_kernel(const int32_t* __restrict__ cond, int B, int C, int boundary,
                                                           float beta, float* __restrict__ Wt,
                                                           int32_t* __restrict__ counts_out,
@@ -71,21 +71,39 @@ __global__ __launch_bounds__(256) void mmd_prepare_kernel(const int32_t* __restr
     if (threadIdx.x == 0) { nlow = 0; nhigh = 0; }
     __syncthreads();
     {
-        const int len = (B + 255) / 256;
-        const int lo = threadIdx.x * len, hi = min(B, lo + len);
-        int cur = -1, n = 0;
-        for (int i = lo; i < hi; ++i) {
-            const int c = cond[i];
-            if (c != cur) {
-                if (n > 0 && cur >= 0 && cur < C) atomicAdd(&cnt[cur], n);
-                cur = c;
-                n = 0;
+        // a run [s, e] of one condition adds (e + 1) - s: two LDS atomics per run, any row order (the sums wrap modulo
+        // 2^32 for heavily fragmented batches; their difference does not).  Conditions are staged 4096 at a time with
+        // all of a thread's loads in flight at once: a single workgroup is latency-bound, not bandwidth-bound.
+        constexpr int CH = 4096;
+        __shared__ int buf[CH + 2];
+        unsigned* ucnt = reinterpret_cast<unsigned*>(cnt);
+        for (int base = 0; base < B; base += CH) {
+            const int n = min(CH, B - base);
+            int v[CH / 256];
+#pragma unroll
+            for (int q = 0; q < CH / 256; ++q) {
+                const int j = threadIdx.x + 256 * q;
+                v[q] = j < n ? cond[base + j] : 0;
             }
-            ++n;
+            if (threadIdx.x == 0) {
+                buf[0] = base > 0 ? cond[base - 1] : INT32_MIN;
+                buf[n + 1] = base + n < B ? cond[base + n] : INT32_MIN;
+            }
+#pragma unroll
+            for (int q = 0; q < CH / 256; ++q)
+                if (threadIdx.x + 256 * q < n) buf[1 + threadIdx.x + 256 * q] = v[q];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < CH / 256; ++q) {
+                const int j = threadIdx.x + 256 * q, c = v[q];
+                if (j < n && c >= 0 && c < C) {
+                    if (buf[j + 2] != c) atomicAdd(&ucnt[c], (unsigned)(base + j + 1));
+                    if (buf[j] != c) atomicSub(&ucnt[c], (unsigned)(base + j));
+                }
+            }
+            __syncthreads();
         }
-        if (n > 0 && cur >= 0 && cur < C) atomicAdd(&cnt[cur], n);
     }
-    __syncthreads();
     const int need = boundary >= 0 ? 2 : 1;
     for (int i = threadIdx.x; i < C; i += 256) {
         const int v = cnt[i] >= need;

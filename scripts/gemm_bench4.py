@@ -12,7 +12,7 @@ for name, am, bm, M, N, K in shapes:
     A = torch.randn(M * K, device='cuda'); Bm = torch.randn(N * K, device='cuda')
     lda = K if am == 0 else M; ldb = K if bm == 0 else N
     res = []
-    for wm, wn in ((1, 1),):
+    for wm, wn in ((2, 2), (1, 2), (2, 1), (1, 1)):
         for S in (1, 2, 4, 8, 16, 32):
             if S > 1 and (K // 32) // S < 2: continue
             C = torch.empty(S * M * N, device='cuda')
