@@ -36,6 +36,10 @@ def parse():
     ap.add_argument("--latent", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--dp-mmd", choices=["local", "exact"], default="local",
+                    help="N > 1 only: MMD over each rank's slice (default: weak scaling keeps the O(B^2) MMD work per "
+                         "GPU fixed) or the reference's MMD over the global minibatch (all-gather of z; O(B_global^2) "
+                         "per rank - meant for the reference's batch sizes, not for 8 x 8192 cells)")
     ap.add_argument("--launch", choices=["auto", "plan", "graph", "eager"], default="auto",
                     help="recorded launch plan, HIP-graph replay, eager launches, or auto (graph for B <= 4096, plan above)")
     return ap.parse_args()
@@ -202,6 +206,8 @@ def main():
                 beta=1.0, dr_rate=0.05, seed=2020 + rank)
     eng = CVAEEngine(spec, P, dev)
     eng.bind_csr(indptr, indices, data)
+    if world > 1:
+        eng.set_dp(rank, world, exact_mmd=(a.dp_mmd == "exact"))
     gen = torch.Generator(device=dev)
     gen.manual_seed(2020 + rank)
 
@@ -241,7 +247,9 @@ def main():
                                f"{data.numel() / n_local:.0f} nnz/cell), {C} conditions, NB loss, MMD on z, hidden {H}, "
                                f"Z={Z}, dropout 0.05, Adam(eps 0.01, wd 0.04)",
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}" if world > 1 else "single",
-                   "launch": a.launch},
+                   "launch": a.launch,
+                   "mmd": "single device" if world == 1 else
+                          ("global minibatch (all-gather of z)" if a.dp_mmd == "exact" else "per-rank slice")},
         "final_losses": {"recon": losses[0], "kl": losses[1], "mmd": losses[2]},
     }
 

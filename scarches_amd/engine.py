@@ -246,6 +246,9 @@ class CVAEEngine:
         self._aux_q = []
         self._rec = None                # launch-plan recorder (train_step)
         self.overlap = True
+        self._dp = None                 # set_dp(): rank / world / exact-MMD switch of data-parallel runs
+        self._dp_ws = {}
+        self._dp_n_global = None
         self.set_hyper(alpha_kl=1.0, lr=1e-3, eps=0.01, clip=0.0)
         # fused middle (fused_mid.hip): trVAE family with LayerNorm / no norm, NB or MSE, narrow hidden layers
         wmax = self.lib.sca_mid_max_width()
@@ -603,7 +606,7 @@ class CVAEEngine:
                          compute_grad=True, eps: Optional[torch.Tensor] = None,
                          masks: Optional[Dict[str, torch.Tensor]] = None, accumulate_logs=True,
                          x_dense: Optional[torch.Tensor] = None, covs: Optional[torch.Tensor] = None,
-                         proto: Optional[dict] = None):
+                         proto: Optional[dict] = None, n_global: Optional[int] = None):
         """One fwd(+bwd) pass over the minibatch `row_ids` (int64 device tensor of CSR row numbers) whose conditions
         are `cond` (int32 device tensor).  Leaves losses in self.losses = [recon, kl, mmd, total] and, when
         compute_grad, the gradients of recon + hyper[0]*kl + mmd in self.flat_g.  Nothing is synchronised."""
@@ -618,6 +621,9 @@ class CVAEEngine:
         step_p = self.step_ctr.data_ptr()
         masks = masks or {}
         self._p_drop_cur, self._masks_cur = p_drop, masks
+        self._cond_cur = cond
+        if n_global is not None:        # data-parallel runs: size of the GLOBAL minibatch this slice belongs to
+            self._dp_n_global = int(n_global)
 
         # 1. minibatch gather (+ log1p, size factors)
         log1p = 0 if self.recon == "mse" else 1
@@ -675,17 +681,11 @@ class CVAEEngine:
 
         def mmd_work(sa):
             feat, Dm = (ws["z"], Z) if self.mmd_on == "z" else (ws["dec0.h"], self.dec[0].n_out)
-            _lib.check(L.sca_mmd_fwd_bwd(feat.data_ptr(), Dm, cond_p, B, Dm, C,
-                                         -1 if self.boundary is None else int(self.boundary), self.beta,
-                                         ws["Wt"].data_ptr(), ws["counts"].data_ptr(), ws["mmd_part"].data_ptr(),
-                                         ws["mmd_g"].data_ptr() if compute_grad else None, B * Dm, sa), "mmd")
-            if compute_grad and L.sca_mmd_num_slabs(B, Dm) > 1:      # gradient slabs summed off the critical path
-                _lib.check(L.sca_splitk_reduce(ws["mmd_g"].data_ptr(), L.sca_mmd_num_slabs(B, Dm), B * Dm,
-                                               ws["mmd_g1"].data_ptr(), B * Dm, sa), "mmd_reduce")
+            self._mmd_launch(sa, feat, Dm, cond, cond_p, B, compute_grad)
 
         def want_mmd():
             Dm = Z if self.mmd_on == "z" else self.dec[0].n_out
-            self._n_part = L.sca_mmd_num_partials(B, Dm)
+            self._n_part = self._mmd_partials(B, Dm)
             self._defer(mmd_work)
 
         if do_mmd and self.mmd_on == "z":
@@ -964,14 +964,8 @@ class CVAEEngine:
         self._n_part = 0
         if do_mmd:
             def mmd_work(sa):
-                _lib.check(L.sca_mmd_fwd_bwd(ws["z"].data_ptr(), Z, cond_p, B, Z, C,
-                                             -1 if self.boundary is None else int(self.boundary), self.beta,
-                                             ws["Wt"].data_ptr(), ws["counts"].data_ptr(), ws["mmd_part"].data_ptr(),
-                                             ws["mmd_g"].data_ptr() if compute_grad else None, B * Z, sa), "mmd")
-                if compute_grad and L.sca_mmd_num_slabs(B, Z) > 1:
-                    _lib.check(L.sca_splitk_reduce(ws["mmd_g"].data_ptr(), L.sca_mmd_num_slabs(B, Z), B * Z,
-                                                   ws["mmd_g1"].data_ptr(), B * Z, sa), "mmd_reduce")
-            self._n_part = L.sca_mmd_num_partials(B, Z)
+                self._mmd_launch(sa, ws["z"], Z, self._cond_cur, cond_p, B, compute_grad)
+            self._n_part = self._mmd_partials(B, Z)
             self._defer(mmd_work)
         ev_side = self._flush()
         Hd = self.dec[-1].n_out
@@ -1224,9 +1218,109 @@ class CVAEEngine:
                                        self.flat_m[s:].data_ptr(), self.flat_v[s:].data_ptr(), e - s,
                                        self.hyper.data_ptr(), 0.9, 0.999, wd, st), "adam")
 
+    # ------------------------------------------------------------------------------------------ data-parallel MMD
+    def set_dp(self, rank: int, world: int, exact_mmd: bool = True, gather=None):
+        """Data-parallel context of this engine.  With `exact_mmd` the MMD of a step is the reference's MMD over the
+        GLOBAL minibatch (scarches/models/trvae/losses.py:231-270 couples every pair of cells): the ranks all-gather
+        their latent rows + conditions (B_global x Z floats), every rank evaluates the full kernel sum - the value is
+        then identical on all ranks - and keeps the gradient rows of its own cells, pre-scaled by n_global / n_local
+        so that the weighted gradient all-reduce (weight n_local / n_global) adds the MMD term with weight 1.
+        Cost: O(B_global^2) pair evaluations PER RANK; meant for the reference's batch sizes (<= a few thousand
+        cells per global minibatch).  Without it each rank takes the MMD of its own slice (a per-rank estimator).
+        `gather(out, local)` replaces torch.distributed.all_gather_into_tensor (tests)."""
+        self._dp = dict(rank=int(rank), world=int(world), exact=bool(exact_mmd) and world > 1, gather=gather)
+        self._plans = {}
+
+    def _dp_exact(self):
+        return self._dp is not None and self._dp["exact"] and self.use_mmd and self.C > 0
+
+    def _dp_bufs(self, n_max, Dm):
+        key = (n_max, Dm)
+        b = self._dp_ws.get(key)
+        if b is None:
+            dev, Bg = self.device, self._dp["world"] * n_max
+            ns = self.lib.sca_mmd_num_slabs(Bg, Dm)
+            b = dict(zpad=torch.zeros(n_max, Dm, device=dev),
+                     cpad=torch.full((n_max,), -1, dtype=torch.int32, device=dev),
+                     zall=torch.empty(Bg, Dm, device=dev), call=torch.empty(Bg, dtype=torch.int32, device=dev),
+                     slabs=torch.empty(max(1, ns) * Bg * Dm, device=dev), ns=ns)
+            b["g1"] = b["slabs"][:Bg * Dm].view(Bg, Dm) if ns == 1 else torch.empty(Bg, Dm, device=dev)
+            self._dp_ws[key] = b
+        return b
+
+    def _dp_gather(self, out, local):
+        if self._dp["gather"] is not None:
+            self._dp["gather"](out, local)
+        else:
+            import torch.distributed as dist
+            dist.all_gather_into_tensor(out, local)
+
+    def _dp_stage_gather(self, b, feat, cond_t, B, Dm, stream):
+        """Pad this rank's rows to n_max (condition -1 = ignored by the kernels) and all-gather rows + conditions."""
+        with torch.cuda.stream(stream):
+            zp, cp = b["zpad"], b["cpad"]
+            if B < zp.shape[0]:
+                zp[B:].zero_()
+                cp[B:].fill_(-1)
+            if B > 0:
+                zp[:B].copy_(feat.view(-1)[:B * Dm].view(B, Dm))
+                cp[:B].copy_(cond_t.view(-1)[:B])
+            self._dp_gather(b["zall"], zp)
+            self._dp_gather(b["call"], cp)
+
+    def _dp_take_rows(self, b, B, Dm, lo, scale, stream):
+        with torch.cuda.stream(stream):
+            torch.mul(b["g1"][lo:lo + B], scale, out=self.ws["mmd_g1"].view(-1)[:B * Dm].view(B, Dm))
+
+    def dp_idle_step(self, n_global):
+        """A rank whose slice of a (tiny, last) minibatch is empty still takes part in the step's all-gathers."""
+        if not self._dp_exact():
+            return
+        Dm = self.Zt if (self.mmd_on == "z" or self.arch == "expimap") else self.dec[0].n_out
+        b = self._dp_bufs(-(-int(n_global) // self._dp["world"]), Dm)
+        self._dp_stage_gather(b, None, None, 0, Dm, torch.cuda.current_stream(self.device))
+
+    def _mmd_launch(self, sa, feat, Dm, cond_t, cond_p, B, compute_grad):
+        """MMD forward (+ gradient w.r.t. the feature rows into ws['mmd_g1']) on stream `sa`."""
+        L, ws, C = self.lib, self.ws, self.C
+        bnd = -1 if self.boundary is None else int(self.boundary)
+        if not self._dp_exact():
+            _lib.check(L.sca_mmd_fwd_bwd(feat.data_ptr(), Dm, cond_p, B, Dm, C, bnd, self.beta,
+                                         ws["Wt"].data_ptr(), ws["counts"].data_ptr(), ws["mmd_part"].data_ptr(),
+                                         ws["mmd_g"].data_ptr() if compute_grad else None, B * Dm, sa), "mmd")
+            if compute_grad and L.sca_mmd_num_slabs(B, Dm) > 1:      # gradient slabs summed off the critical path
+                _lib.check(L.sca_splitk_reduce(ws["mmd_g"].data_ptr(), L.sca_mmd_num_slabs(B, Dm), B * Dm,
+                                               ws["mmd_g1"].data_ptr(), B * Dm, sa), "mmd_reduce")
+            return
+        d = self._dp
+        n_global = int(self._dp_n_global or B * d["world"])
+        n_max = -(-n_global // d["world"])
+        Bg = d["world"] * n_max
+        b = self._dp_bufs(n_max, Dm)
+        stream = self.aux if (self.overlap and sa == self.aux.cuda_stream) else torch.cuda.current_stream(self.device)
+        self._call(self._dp_stage_gather, b, feat, cond_t, B, Dm, stream)
+        _lib.check(L.sca_mmd_fwd_bwd(b["zall"].data_ptr(), Dm, b["call"].data_ptr(), Bg, Dm, C, bnd, self.beta,
+                                     ws["Wt"].data_ptr(), ws["counts"].data_ptr(), ws["mmd_part"].data_ptr(),
+                                     b["slabs"].data_ptr() if compute_grad else None, Bg * Dm, sa), "mmd[dp]")
+        if compute_grad:
+            if b["ns"] > 1:
+                _lib.check(L.sca_splitk_reduce(b["slabs"].data_ptr(), b["ns"], Bg * Dm, b["g1"].data_ptr(), Bg * Dm, sa),
+                           "mmd_reduce[dp]")
+            self._call(self._dp_take_rows, b, B, Dm, d["rank"] * n_max, n_global / float(B), stream)
+
+    def _mmd_partials(self, B, Dm):
+        """Number of loss partials the MMD launch of this step writes (ws['mmd_part'] is grown to hold them)."""
+        if self._dp_exact():
+            d = self._dp
+            B = d["world"] * -(-int(self._dp_n_global or B * d["world"]) // d["world"])
+        n = self.lib.sca_mmd_num_partials(B, Dm)
+        if self.ws["mmd_part"].numel() < n:
+            self.ws["mmd_part"] = torch.zeros(n, dtype=torch.float64, device=self.device)
+        return n
+
     # ------------------------------------------------------------------------------------------ whole step
     def train_step(self, row_ids, cond, B, alpha_kl, lr, eps=0.01, clip=0.0, weight_decay=0.04, world=1,
-                   use_graph="auto", wd_overrides=None, grad_weight=None):
+                   use_graph="auto", wd_overrides=None, grad_weight=None, n_global=None):
         """One optimisation step: forward + backward (+ gradient all-reduce) + Adam.
 
         All per-step scalars live in device memory (`hyper`, `step_ctr`) and the minibatch ids are copied into static
@@ -1240,6 +1334,15 @@ class CVAEEngine:
           * False  : launched eagerly through the normal Python path."""
         if use_graph == "auto":
             use_graph = True if B <= 4096 else "plan"
+        dp_exact = world > 1 and self._dp_exact()
+        if dp_exact:
+            self._dp_n_global = int(n_global) if n_global is not None else B * world
+            if use_graph is True:       # the step holds two all-gathers: recorded launch plan, no graph capture
+                use_graph = "plan"
+            if self._dp_n_global != B * world:
+                # ragged last minibatch: ranks see different local sizes (or none: dp_idle_step), so nobody records a
+                # plan - recording replays the step twice, and every rank must issue the same number of collectives
+                use_graph = False
         if use_graph is False:
             self.begin_step(alpha_kl, lr, eps, clip)
             self.forward_backward(row_ids, cond, B)
@@ -1250,7 +1353,8 @@ class CVAEEngine:
             return self.losses
         key = (B, use_graph is True, float(weight_decay), tuple(sorted((wd_overrides or {}).items())), world > 1,
                tuple(sorted(k for k, v in self.trainable.items() if v)), self.use_mmd, self.mmd_on, self.boundary,
-               self.beta, torch.cuda.current_stream(self.device).cuda_stream)
+               self.beta, torch.cuda.current_stream(self.device).cuda_stream,
+               self._dp_n_global if dp_exact else None)
         plans = self.__dict__.setdefault("_plans", {})
         g = plans.get(key)
         fast = (g is not None and row_ids.dtype == torch.int64 and cond.dtype == torch.int32 and row_ids.is_cuda

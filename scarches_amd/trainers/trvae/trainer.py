@@ -10,8 +10,10 @@ synchronisation; per-iteration losses are accumulated on the device and read onc
 Data parallelism (new, the reference is single-device): when torch.distributed is initialised with world_size > 1,
 each rank keeps a strided shard of the training cells, `batch_size` is the GLOBAL minibatch (batch_size // world per
 rank), gradients are averaged with one all-reduce of the flat buffer per step and the epoch log sums are all-reduced
-so every rank takes the same early-stopping / LR decision.  MMD is evaluated per rank on its local slice of the
-minibatch (a different - still unbiased per condition pair - estimator than the single-device global one).
+so every rank takes the same early-stopping / LR decision.  The MMD couples all cells of a minibatch: by default
+(`dp_exact_mmd=True`) the ranks all-gather their latent rows and every rank evaluates the reference's MMD over the
+GLOBAL minibatch (identical losses and gradients to a single-device run, CVAEEngine.set_dp); `dp_exact_mmd=False`
+takes the MMD of each rank's slice instead (a per-rank estimator: no collective, O(B_local^2) work).
 """
 import logging
 import time
@@ -64,6 +66,7 @@ class Trainer:
         # how the engine issues a step: "auto" (HIP graph for small batches, recorded launch plan above), "plan",
         # True (graph) or False (eager Python launches)
         self.launch_mode = kwargs.pop("launch_mode", "auto")
+        self.dp_exact_mmd = kwargs.pop("dp_exact_mmd", True)
         self.early_stopping = EarlyStopping(**early_stopping_kwargs)
 
         torch.manual_seed(self.seed)
@@ -155,6 +158,8 @@ class Trainer:
         self.model.train()
         self.n_epochs = n_epochs
         self.engine = self.model.engine(self.device)          # also syncs requires_grad -> trainable set
+        if self.world > 1:
+            self.engine.set_dp(self.rank, self.world, exact_mmd=self.dp_exact_mmd)
         self.optimizer = _ParamGroups(lr, eps, self.weight_decay)
         self._eps = eps
         tr = self._train_dev
@@ -200,13 +205,15 @@ class Trainer:
                   clip=self.clip_value)
         if rows.numel() == 0:           # a rank whose slice of a tiny last minibatch is empty contributes zeros
             eng.begin_step(**kw)
+            eng.dp_idle_step(n_global)
             eng.flat_g.zero_()
             sdist.allreduce_mean_(eng.flat_g, self.world, weight=0.0)
             eng.adam_step(weight_decay=self.weight_decay)
             return
         self.current_loss = eng.train_step(rows, cond, rows.numel(), weight_decay=self.weight_decay,
                                            world=self.world, use_graph=self.launch_mode,
-                                           grad_weight=rows.numel() / n_global if self.world > 1 else None, **kw)
+                                           grad_weight=rows.numel() / n_global if self.world > 1 else None,
+                                           n_global=n_global if self.world > 1 else None, **kw)
 
     def _read_logs(self, prefix):
         acc = self.engine.accum.clone()
@@ -241,16 +248,18 @@ class Trainer:
         eng.set_hyper(alpha_kl=self.calc_alpha_coeff())
         for lo in range(0, n, self._val_batch):
             b = perm[lo:lo + self._val_batch]
+            n_global = b.numel()
             if self.world > 1:
                 s, e = sdist.shard_range(b.numel(), self.rank, self.world)
                 b = b[s:e]
                 if b.numel() == 0:
+                    eng.dp_idle_step(n_global)
                     continue
             c = va["cond"][b]
             order = torch.argsort(c, stable=True)
             eng.step_ctr += 1
             eng.forward_backward(b[order].contiguous(), c[order].contiguous(), b.numel(), train=False,
-                                 compute_grad=False)
+                                 compute_grad=False, n_global=n_global if self.world > 1 else None)
         self._read_logs("val_")
         self.model.train()
 

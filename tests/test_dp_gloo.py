@@ -3,6 +3,8 @@
 * every rank draws the same global sample and keeps a disjoint slice that covers the minibatch;
 * the weighted gradient all-reduce reproduces the single-process global-minibatch gradient (checked with the oracle's
   autograd gradients as the per-rank inputs, ragged shards included);
+* the exact-MMD recipe of CVAEEngine.set_dp (padded all-gather of latent rows, full MMD per rank, own rows scaled by
+  n_global / n_local) reproduces the single-process gradient including the MMD term;
 * summed epoch logs give every rank the same early-stopping / LR decision.
 """
 import os
@@ -68,6 +70,34 @@ def _worker(rank, port, out_dir):
     ref = torch.cat([g_glob[k].reshape(-1) for k in names])
     res["grad_err_equal"] = float((flat - ref).abs().max() / ref.abs().max())
 
+    # ---- (2b) exact MMD under DP (CVAEEngine.set_dp): all-gather of the padded latent rows + conditions (padding
+    # rows carry condition -1), full MMD on every rank, own rows differentiable, scaled by n_global / n_local so the
+    # weighted all-reduce adds it with weight 1  ==  the single-process gradient WITH the MMD term (ragged 8 + 7)
+    cfg_m = dict(cfg, use_mmd=True, mmd_on="z")
+    res_glob, g_glob, _ = O.trvae_loss_and_grads(W, cfg_m, x, cond, sf, eps, alpha)
+    lo, hi = sdist.shard_range(15, rank, WORLD)
+    n_loc, n_max = hi - lo, -(-15 // WORLD)
+    P = {k: torch.tensor(np.asarray(v)).requires_grad_(True) for k, v in W.items()}
+    recon, kl, _, aux = O.trvae_forward(P, dict(cfg_m, use_mmd=False), x[lo:hi].float(),
+                                        torch.as_tensor(cond[lo:hi]).long(), sf[lo:hi].float(), eps[lo:hi].float())
+    zpad = torch.zeros(n_max, cfg["Z"])
+    cpad = torch.full((n_max,), -1, dtype=torch.int32)
+    zpad[:n_loc] = aux["z"].detach()
+    cpad[:n_loc] = torch.as_tensor(cond[lo:hi]).int()
+    zall, call = torch.empty(WORLD * n_max, cfg["Z"]), torch.empty(WORLD * n_max, dtype=torch.int32)
+    dist.all_gather_into_tensor(zall, zpad)
+    dist.all_gather_into_tensor(call, cpad)
+    blocks = [aux["z"] if r == rank else zall[r * n_max:(r + 1) * n_max] for r in range(WORLD)]
+    blocks[rank] = torch.cat([aux["z"], torch.zeros(n_max - n_loc, cfg["Z"])])
+    zcat, keep = torch.cat(blocks), call >= 0
+    mmd = O.mmd_loss(zcat[keep], call[keep].long(), cfg["C"], cfg["beta"], cfg["boundary"])
+    (recon + alpha * kl + (15 / n_loc) * mmd).backward()
+    flat = torch.cat([(P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])).reshape(-1) for k in names])
+    sdist.allreduce_mean_(flat, WORLD, weight=n_loc / 15)
+    ref = torch.cat([g_glob[k].reshape(-1) for k in names])
+    res["grad_err_mmd"] = float((flat - ref).abs().max() / ref.abs().max())
+    res["mmd_err"] = abs(float(mmd) - res_glob["mmd"]) / abs(res_glob["mmd"])
+
     # ---- (3) summed logs -> identical early-stopping decisions on every rank
     rng = np.random.default_rng(100 + rank)          # different local validation losses
     es = EarlyStopping(patience=4, lr_patience=2)
@@ -97,6 +127,7 @@ def test_dp_two_ranks_gloo(tmp_path):
         assert res["cover"]
         assert res["grad_err"] < 1e-5, res           # fp32 association noise only
         assert res["grad_err_equal"] < 1e-5, res
+        assert res["grad_err_mmd"] < 1e-5 and res["mmd_err"] < 1e-5, res
         assert res["same_decisions"] and res["stopped"]
 
 
