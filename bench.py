@@ -187,11 +187,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a one-GPU box (tests/test_gpu_bench_dp.py): every rank on GPU 0, gloo instead of RCCL
+    rehearsal = os.environ.get("SCA_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("SCA_BENCH_HANG_S", "100")), exit=True)      # a hung collective names itself instead of timing out
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     from scarches_amd.engine import CVAEEngine
     from scarches_amd.synth import make_synthetic_csr
     from scarches_amd import distributed as sdist
@@ -254,6 +263,7 @@ def main():
     }
 
     if rank == 0:
+        eng._dp = None      # the replays below run on rank 0 only: no collective may be part of them
         # ---- roofline of the dominant kernel family: the fp32 MFMA GEMMs of one step, replayed under HIP events
         eng.record_gemms = []
         ids, cs = epoch_batches(cond_all, 1, B, gen)

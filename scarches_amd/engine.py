@@ -1337,12 +1337,12 @@ class CVAEEngine:
         dp_exact = world > 1 and self._dp_exact()
         if dp_exact:
             self._dp_n_global = int(n_global) if n_global is not None else B * world
-            if use_graph is True:       # the step holds two all-gathers: recorded launch plan, no graph capture
-                use_graph = "plan"
-            if self._dp_n_global != B * world:
-                # ragged last minibatch: ranks see different local sizes (or none: dp_idle_step), so nobody records a
-                # plan - recording replays the step twice, and every rank must issue the same number of collectives
-                use_graph = False
+            # The step holds two all-gathers in its middle: it is launched eagerly.  (Every rank must issue the same
+            # collectives in the same order: a ragged last minibatch gives the ranks different local sizes - or none,
+            # dp_idle_step - so ranks would record plans at different steps, and recording runs the step twice.  A
+            # replayed plan with the gathers as host calls also hung in the two-rank rehearsal of bench.py over gloo,
+            # where the eager step runs; not understood, so not shipped.)
+            use_graph = False
         if use_graph is False:
             self.begin_step(alpha_kl, lr, eps, clip)
             self.forward_backward(row_ids, cond, B)

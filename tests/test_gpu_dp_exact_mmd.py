@@ -7,8 +7,9 @@ one after the other on ragged slices (334 / 334 / 333 cells, so padding rows wit
 all-gather is replaced by a function that assembles what the other ranks would have sent (from a single-device run of
 the whole minibatch), and   sum_r (n_r / n) * grad_r   must equal the single-device gradient of the whole minibatch,
 the MMD value on every rank must equal the single-device value.  Both launch paths (fused middle kernels, and MMD on the
-first decoder layer 'y' through the per-layer path) are covered, as is the recorded-plan replay.  The collective itself
-(torch.distributed.all_gather_into_tensor over RCCL) is a one-line call and is not exercised here."""
+first decoder layer 'y' through the per-layer path) are covered.  The collective itself
+(torch.distributed.all_gather_into_tensor) runs for real in tests/test_gpu_bench_dp.py (two gloo ranks on one GPU) and
+tests/test_dp_gloo.py (CPU)."""
 import numpy as np
 import pytest
 import torch
@@ -110,10 +111,9 @@ def test_exact_dp_mmd_matches_single_device(data, mmd_on):
     assert_grads_close(acc, gf, rtol=2e-4)
 
 
-def test_exact_dp_train_step_records_and_replays_the_gathers(data):
-    """train_step under exact DP MMD: an even global minibatch records a launch plan (warm-up + recording = two extra
-    passes, on every rank alike) whose replay issues exactly one gather pair per step, gives the same trajectory as
-    eager launches, and a requested HIP graph is demoted to the plan; a ragged one is launched eagerly (one pair)."""
+def test_exact_dp_train_step_is_eager_with_one_gather_pair_per_step(data):
+    """train_step under exact DP MMD launches eagerly whatever launch mode is asked for (every rank issues exactly one
+    gather pair per step, ragged minibatch or not) and all modes give the same trajectory."""
     import torch.distributed as dist
     if not dist.is_initialized():
         import os
@@ -154,12 +154,12 @@ def test_exact_dp_train_step_records_and_replays_the_gathers(data):
 
     c_eager, l_eager, p_eager = run(False, n * WORLD)
     assert c_eager == [2, 4, 6]
-    for mode in ("plan", True):
+    for mode in ("plan", True, "auto"):
         c, l, p = run(mode, n * WORLD)
-        assert c == [6, 8, 10], c           # warm-up + recording + the step itself, then one pair per replay
+        assert c == [2, 4, 6], c
         assert np.all(np.abs(l[:3] - l_eager[:3]) <= 1e-4 * np.abs(l_eager[:3])), (mode, l, l_eager)
         assert float((p - p_eager).abs().max()) <= 1e-4 * float(p_eager.abs().max())
-    c, _, _ = run("plan", n * WORLD + 1)   # ragged: eager
+    c, _, _ = run("plan", n * WORLD + 1)   # ragged
     assert c == [2, 4, 6]
 
 
