@@ -52,15 +52,15 @@ def make_engine(data, **over):
     return eng
 
 
-@pytest.mark.parametrize("mmd_on", ["z", "y"])
-def test_exact_dp_mmd_matches_single_device(data, mmd_on):
+@pytest.mark.parametrize("mmd_on,boundary", [("z", None), ("y", None), ("z", 2)])
+def test_exact_dp_mmd_matches_single_device(data, mmd_on, boundary):
     sizes = [s[0].numel() for s in data["slices"]]
     assert sizes == [334, 334, 333]
     n_max = max(sizes)
     rows_full = torch.cat([s[0] for s in data["slices"]])
     cond_full = torch.cat([s[1] for s in data["slices"]])
     # ---- single device, whole minibatch
-    full = make_engine(data, mmd_on=mmd_on)
+    full = make_engine(data, mmd_on=mmd_on, boundary=boundary)
     full.begin_step(alpha_kl=0.5, lr=1e-3)
     full.forward_backward(rows_full, cond_full, NG, eps=data["eps"])
     torch.cuda.synchronize()
@@ -93,7 +93,7 @@ def test_exact_dp_mmd_matches_single_device(data, mmd_on):
             out.copy_(exp)
             calls.append(local.dtype)
 
-        e = make_engine(data, mmd_on=mmd_on)
+        e = make_engine(data, mmd_on=mmd_on, boundary=boundary)
         e.set_dp(r, WORLD, exact_mmd=True, gather=gather)
         eps_r = data["eps"][lo:lo + n].contiguous()
         e.begin_step(alpha_kl=0.5, lr=1e-3)
