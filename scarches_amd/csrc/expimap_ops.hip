@@ -39,7 +39,58 @@ __global__ __launch_bounds__(256) void prox_l1_kernel(float* __restrict__ W, lon
 
 // ProxGroupLasso over the columns of W [rows][cols]: n_c = ||W[:, c]||_2, coeff_c = alpha * (omega ? omega[c] : 1);
 //   W[:, c] <- (W[:, c] - W[:, c] / s_c) * [n_c > coeff_c],  s_c = n_c / coeff_c (+1 when not > 0).
-// A workgroup owns 64 columns: lanes = columns (coalesced rows), the 4 waves split the rows.
+// Three small launches over the whole matrix instead of one workgroup per 64 columns (5 workgroups walked the
+// 5000 x 280 decoder of the expiMap benchmark in 546 us): clear the column sums, accumulate them from 64-column x
+// 64-row tiles (one float atomic per column and tile), apply.  The column sums live in a file-scope device array
+// (kernels name it directly; the host never takes its address): calls that overlap on one GPU would race on it -
+// the engine issues its proximal steps on one stream.  Matrices with more columns take the one-launch kernel.
+constexpr int PROX_MAX_COLS = 16384;
+constexpr int PROX_ROWS = 64;              // rows per tile of the accumulate / apply kernels
+__device__ float g_prox_colsq[PROX_MAX_COLS];
+
+__global__ __launch_bounds__(256) void prox_gl_clear_kernel(int cols) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < cols) g_prox_colsq[c] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void prox_gl_sumsq_kernel(const float* __restrict__ W, int rows, int cols) {
+    __shared__ float part[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int r0 = blockIdx.y * PROX_ROWS, r1 = min(rows, r0 + PROX_ROWS);
+    float ss = 0.f;
+    if (c < cols)
+#pragma unroll 4
+        for (int r = r0 + ry; r < r1; r += 4) {
+            const float w = W[(long long)r * cols + c];
+            ss = fmaf(w, w, ss);
+        }
+    part[ry][cx] = ss;
+    __syncthreads();
+    if (ry == 0 && c < cols) atomicAdd(&g_prox_colsq[c], (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]));
+}
+
+__global__ __launch_bounds__(256) void prox_gl_apply_kernel(float* __restrict__ W, int rows, int cols, float alpha,
+                                                            const float* __restrict__ omega) {
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    if (c >= cols) return;
+    const int r0 = blockIdx.y * PROX_ROWS, r1 = min(rows, r0 + PROX_ROWS);
+    const float norm = sqrtf(g_prox_colsq[c]);
+    const float coeff = alpha * (omega ? omega[c] : 1.f);
+    const float keep = norm > coeff ? 1.f : 0.f;
+    float s = norm / coeff;
+    if (!(s > 0.f)) s += 1.f;
+#pragma unroll 4
+    for (int r = r0 + ry; r < r1; r += 4) {
+        const long long o = (long long)r * cols + c;
+        float w = W[o];
+        w -= w / s;
+        W[o] = w * keep;
+    }
+}
+
+// One-launch variant (any number of columns): a workgroup owns 64 columns, lanes = columns, the 4 waves split the rows.
 __global__ __launch_bounds__(256) void prox_group_lasso_kernel(float* __restrict__ W, int rows, int cols, float alpha,
                                                                const float* __restrict__ omega) {
     __shared__ float part[4][64];
@@ -200,8 +251,16 @@ extern "C" int sca_prox_l1(float* W, long long n, float alpha, const float* I, v
 
 extern "C" int sca_prox_group_lasso(float* W, int rows, int cols, float alpha, const float* omega, void* stream) {
     if (rows <= 0 || cols <= 0) return 0;
-    hipLaunchKernelGGL(prox_group_lasso_kernel, dim3((cols + 63) / 64), dim3(256), 0, (hipStream_t)stream, W, rows,
-                       cols, alpha, omega);
+    hipStream_t st = (hipStream_t)stream;
+    if (cols <= PROX_MAX_COLS && rows > 4 * PROX_ROWS) {
+        const dim3 grid((cols + 63) / 64, (rows + PROX_ROWS - 1) / PROX_ROWS);
+        hipLaunchKernelGGL(prox_gl_clear_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, cols);
+        hipLaunchKernelGGL(prox_gl_sumsq_kernel, grid, dim3(256), 0, st, W, rows, cols);
+        hipLaunchKernelGGL(prox_gl_apply_kernel, grid, dim3(256), 0, st, W, rows, cols, alpha, omega);
+    } else {
+        hipLaunchKernelGGL(prox_group_lasso_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, W, rows, cols, alpha,
+                           omega);
+    }
     SCA_CHECK_LAUNCH();
     return 0;
 }

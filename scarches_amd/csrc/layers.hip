@@ -253,14 +253,16 @@ __global__ __launch_bounds__(256) void latent_fwd_kernel(const LatentArgs a, int
     }
 }
 
-// Wide latents (Z > 256): one thread per row.
+// Wide latents (Z > 256, e.g. expiMap: one latent per gene program): one wave per row, lanes walk the row (coalesced),
+// the KL row sum is one wave reduction.
 __global__ __launch_bounds__(256) void latent_fwd_row_kernel(const LatentArgs a) {
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= a.B) return;
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= a.B) return;                  // wave-uniform
     const int Z = a.Z;
     const uint32_t stp = a.step ? a.step[0] : 0u;
     float kl = 0.f;
-    for (int k = 0; k < Z; ++k) {
+    for (int k = lane; k < Z; k += 64) {
         float mu = a.bias ? a.bias[k] : 0.f, lv = a.bias ? a.bias[Z + k] : 0.f;
         for (int s = 0; s < a.S; ++s) {
             const float* p = a.heads + s * a.slab_stride + (long long)b * 2 * Z;
@@ -288,7 +290,8 @@ __global__ __launch_bounds__(256) void latent_fwd_row_kernel(const LatentArgs a)
         if (a.eps_out) a.eps_out[(long long)b * Z + k] = e;
         a.z[(long long)b * Z + k] = fmaf(e, sd, mu);
     }
-    if (a.kl_row) a.kl_row[b] = kl;
+    kl = wave_sum(kl);
+    if (lane == 0 && a.kl_row) a.kl_row[b] = kl;
 }
 
 struct LatentBwdArgs {
@@ -387,7 +390,7 @@ extern "C" int sca_latent_fwd(const float* heads, int S, long long slab_stride, 
         const int rpb = 256 / Zp;
         hipLaunchKernelGGL(latent_fwd_kernel, dim3((B + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream, a, Zp);
     } else {
-        hipLaunchKernelGGL(latent_fwd_row_kernel, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(latent_fwd_row_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, a);
     }
     SCA_CHECK_LAUNCH();
     return 0;

@@ -254,3 +254,32 @@ def test_adam_kernel(lib):
         O.adam_step(pr, g, mr, vr, t, lr=1e-3, eps=0.01, wd=0.04)
     torch.cuda.synchronize()
     assert (pd_.cpu() - pr).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("Z", [10, 256, 280, 513])
+def test_latent_fwd_narrow_and_wide_rows(Z):
+    """sca_latent_fwd against the reference formulas in torch (models/base/_base.py:391-407 sampling,
+    models/trvae/trvae.py:143-147 KL): the narrow kernel (Z <= 256) and the one-wave-per-row kernel that expiMap's wide
+    latents (one per gene program, e.g. 280) take; two split-K slabs, bias, injected noise, ragged B."""
+    from scarches_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    B, S = 1031, 2
+    gen = torch.Generator(device="cuda").manual_seed(Z)
+    heads = torch.randn(S, B, 2 * Z, device="cuda", generator=gen) * 0.3
+    bias = torch.randn(2 * Z, device="cuda", generator=gen) * 0.1
+    eps = torch.randn(B, Z, device="cuda", generator=gen)
+    mu_lv, eo, z, kl = (torch.empty(B, 2 * Z, device="cuda"), torch.empty(B, Z, device="cuda"),
+                        torch.empty(B, Z, device="cuda"), torch.empty(B, device="cuda"))
+    _lib.check(lib.sca_latent_fwd(heads.data_ptr(), S, B * 2 * Z, bias.data_ptr(), B, Z, eps.data_ptr(), 0, 0, None, 1,
+                                  mu_lv.data_ptr(), eo.data_ptr(), z.data_ptr(), kl.data_ptr(), st), "latent_fwd")
+    torch.cuda.synchronize()
+    h = (heads.double().sum(0) + bias.double())
+    mu, lv = h[:, :Z], h[:, Z:]
+    var = lv.exp() + 1e-4
+    z_ref = mu + eps.double() * var.sqrt()
+    kl_ref = (0.5 * (var + mu * mu - 1 - var.log())).sum(1)
+    assert float((mu_lv.double() - h).abs().max()) <= 1e-6
+    assert torch.equal(eo, eps)
+    assert float((z.double() - z_ref).abs().max()) <= 1e-5
+    assert float(((kl.double() - kl_ref).abs() / kl_ref.abs().clamp_min(1e-3)).max()) <= 1e-5
