@@ -159,7 +159,9 @@ def test_nb_rows_against_oracle(lib):
     from oracle import cvae_oracle as O
     import scipy.sparse as sp
     rng = np.random.default_rng(5)
-    for (B, G, C, zinb) in [(9, 37, 3, 0), (33, 300, 5, 0), (6, 2000, 4, 0), (17, 130, 3, 1), (5, 2500, 2, 0)]:
+    # (B = 150 with 150 / 70 rows per workgroup: the kernel fetches row scalars 64 rows at a time and refills)
+    for (B, G, C, zinb) in [(9, 37, 3, 0), (33, 300, 5, 0), (6, 2000, 4, 0), (17, 130, 3, 1), (5, 2500, 2, 0),
+                            (150, 90, 4, 0), (150, 90, 4, 1)]:
         x = rng.poisson(rng.gamma(0.3, 3.0, size=(B, G))).astype(np.float32)
         x[0, :] = 0
         if G > 10:
@@ -189,7 +191,7 @@ def test_nb_rows_against_oracle(lib):
         dthT = torch.zeros(C, G, device="cuda")
         db = torch.zeros(G, device="cuda")
         dbp = torch.zeros(G, device="cuda")
-        for rpb in (1, 4):
+        for rpb in (1, 4) if B < 100 else (1, 70, 150):
             ld.copy_(torch.tensor(logits)); pd_.copy_(torch.tensor(pi)); dthT.zero_(); db.zero_(); dbp.zero_()
             _lib.check(lib.sca_recon_rows(zinb, ld.data_ptr(), G, pd_.data_ptr() if zinb else None,
                                           dev(xs.indptr, torch.int64).data_ptr(), dev(xs.indices, torch.int32).data_ptr(),
