@@ -217,6 +217,8 @@ int sca_bn_bwd(const float* dh, int S, long long slab_stride, const float* extra
  * gradient back through the masks (autograd of weight*mask).
  * sca_prox_l1 / sca_prox_group_lasso: ProxL1 / ProxGroupLasso (trainers/expimap/regularized.py:35-58, 5-32) in place
  * on a [rows][cols] weight; I (optional) has the weight's shape, entries != 0 are left untouched; omega: [cols].
+ * sca_prox_group_lasso keeps its column sums of squares (rows > 256, cols <= 16384) in a 64 KB device array of the
+ * library: two calls that overlap on one GPU (different streams) race on it; issue them on one stream.
  * sca_hsic_fwd_bwd: hsic(z[:, side==0], z[:, side==1]) (models/expimap/losses.py:23-31) with RBF bandwidths sigma_a /
  * sigma_b (losses.py:15-21, computed by the caller); writes (accumulate=0) or adds (accumulate=1) weight*hsic into
  * loss_weighted[0] (double) and hsic into loss_raw[0], and ADDS weight * d hsic / d z into dz (may be NULL).
