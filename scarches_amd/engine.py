@@ -1333,7 +1333,10 @@ class CVAEEngine:
                      against 0.37 ms eager) - "auto" for B <= 4096 (0.46 ms at B=4096, where the plan is bimodal);
           * False  : launched eagerly through the normal Python path."""
         if use_graph == "auto":
-            use_graph = True if B <= 4096 else "plan"
+            # world > 1: the gradient all-reduce is a host call between the two halves of the step.  Graph replays
+            # around it hung in the two-rank rehearsal of bench.py (gloo, both ranks on one GPU) where the plan and
+            # the eager step run, so "auto" only picks the graph for the single-process step.
+            use_graph = True if (B <= 4096 and world == 1) else "plan"
         dp_exact = world > 1 and self._dp_exact()
         if dp_exact:
             self._dp_n_global = int(n_global) if n_global is not None else B * world
