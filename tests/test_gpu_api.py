@@ -198,3 +198,31 @@ def test_batchnorm_model_trains_and_freezes_running_stats(tmp_path):
         q.train(n_epochs=3, batch_size=128, use_early_stopping=False, monitor=False, weight_decay=0)
     assert torch.equal(q.model.state_dict()["encoder.FC.N0.running_mean"].cpu(), rm0)
     assert np.isfinite(q.get_latent(mean=True)).all()
+
+
+def test_adaptors_rebuild_query_model_on_device(trained, tmp_path):
+    """`Adaptor` + `attach_adaptors` (models/trvae/adaptors.py) with parameters living in the engine's flat HBM
+    buffer: the adaptors of the two query studies, attached to the reference model, give a model that maps the query
+    cells exactly like the surgery-trained query model (frozen surgery only moves the adaptor's tensors)."""
+    from scarches_amd.models import TRVAE, Adaptor, attach_adaptors
+    m, ad, adq, init = trained
+    with contextlib.redirect_stdout(io.StringIO()):
+        q = TRVAE.load_query_data(adq, m)
+        q.train(n_epochs=3, batch_size=128, alpha_epoch_anneal=10, weight_decay=0, monitor=False,
+                early_stopping_kwargs=dict(patience=50))
+    zq = q.get_latent(mean=True)
+    new = [c for c in q.conditions_ if c not in m.conditions_]
+    paths = []
+    for c in new:
+        a = Adaptor(q, c)
+        assert all(v.shape[1] == 1 for v in a.cond_params.values())
+        paths.append(str(tmp_path / f"adaptor_{c}"))
+        a.save(paths[-1])
+    zr = m.get_latent(mean=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        big = attach_adaptors(m, [paths[0], Adaptor(q, new[1])])
+    assert big.conditions_ == m.conditions_ + new and big.model.n_conditions == len(m.conditions_) + 2
+    z_big = big.get_latent(adq.X, adq.obs["study"], mean=True)
+    assert np.allclose(z_big, zq, rtol=1e-6, atol=1e-6)
+    assert np.allclose(big.get_latent(ad.X, ad.obs["study"], mean=True), zr, atol=1e-6)
+    assert np.allclose(m.get_latent(mean=True), zr, atol=0)           # the passed model still works, unchanged
