@@ -119,6 +119,16 @@ int sca_mmd_num_partials(int B, int D);
 int sca_mmd_fwd_bwd(const float* feat, int ld, const int32_t* cond, int B, int D, int C, int boundary, float beta,
                     float* Wt, int32_t* counts, double* loss_part, float* grad_slabs, long long slab_stride,
                     void* stream);
+/* Row-block form for data-parallel training (same reference lines; SURVEY 8(e) exception 1: the reference's MMD
+ * couples every pair of cells of the global minibatch).  feat / cond hold the all-gathered minibatch [B]; the launch
+ * evaluates rows [row_lo, row_lo + row_n) against all B columns: loss partials = the block's share of the MMD (the
+ * shares of all blocks add up to the whole-minibatch value), gradient slabs [row_n][D] for the block's rows.
+ * Conditions outside [0, C) mark padding rows and are ignored.  beta scales value and gradient linearly. */
+int sca_mmd_rows_num_slabs(int B, int row_n, int D);
+int sca_mmd_rows_num_partials(int B, int row_n, int D);
+int sca_mmd_rows_fwd_bwd(const float* feat, int ld, const int32_t* cond, int B, int D, int C, int boundary, float beta,
+                         float* Wt, int32_t* counts, int row_lo, int row_n, double* loss_part, float* grad_slabs,
+                         long long slab_stride, void* stream);
 
 /* ---- optimiser / bookkeeping ---------------------------------------------------------------------------------
  * hyper (device, float[8]): [0] alpha_kl  [1] lr  [2] 1-beta1^t  [3] sqrt(1-beta2^t)  [4] adam eps  [5] clip value.

@@ -79,6 +79,9 @@ SIGNATURES = {
     "sca_mmd_num_slabs": [I, I],
     "sca_mmd_num_partials": [I, I],
     "sca_mmd_fwd_bwd": [P, I, P, I, I, I, I, F, P, P, P, P, LL, P],
+    "sca_mmd_rows_num_slabs": [I, I, I],
+    "sca_mmd_rows_num_partials": [I, I, I],
+    "sca_mmd_rows_fwd_bwd": [P, I, P, I, I, I, I, F, P, P, I, I, P, P, LL, P],
     "sca_adam_step": [P, P, P, P, LL, P, F, F, F, P],
     "sca_finalize_losses": [P, F, P, I, P, I, P, P, P, P],
     "sca_begin_step": [P, P, F, F, F, F, F, F, P],

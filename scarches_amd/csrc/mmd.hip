@@ -249,11 +249,17 @@ constexpr int MMD_PLD = 65;   // row pitch of the coefficient tile (conflict-fre
 // pairs.  Column gradients are added into slab 0 of `grad` with float atomics (zeroed by mmd_prepare_kernel), once
 // per chunk after an LDS sum over the four waves; row gradients are plain stores into the slab of the workgroup's
 // column range (workgroups below the diagonal store zeros), so the consumer sums 1 + gridDim.y slabs.
-template <int DMAX>
+//
+// ROWS = true is the row-block form for data-parallel training (SURVEY 8(e) exception 1): the launch owns rows
+// [row_lo, row_lo + row_n) of the all-gathered minibatch and walks ALL columns - every tile is treated like a diagonal
+// tile (ordered pairs, weight 1, no transposed pass, no column gradients), loss partials are the block's share
+// sum_{i in block} sum_j Wt K and `grad` holds gridDim.y slabs of [row_n][D] row gradients (local row index).
+template <int DMAX, bool ROWS>
 __global__ __launch_bounds__(256) void mmd_small_kernel(const float* __restrict__ z, int ldz,
                                                         const int32_t* __restrict__ cond, int B, int D, int C,
                                                         const float* __restrict__ Wt, double* __restrict__ loss_part,
-                                                        float* __restrict__ grad, long long slab_stride, int JR) {
+                                                        float* __restrict__ grad, long long slab_stride, int JR,
+                                                        int row_lo, int row_n) {
     constexpr int KH = (DMAX + 1) / 2;        // features per half-wave in the transposed pass
     constexpr int ZS = ((KH + 1 + 3) / 4) * 4;                          // floats per (row, half) in the staged rows
     __shared__ __attribute__((aligned(16))) float zis[4][MMD_T * 2 * ZS];
@@ -263,15 +269,17 @@ __global__ __launch_bounds__(256) void mmd_small_kernel(const float* __restrict_
     __shared__ double redd[16];
     static_assert(MMD_TC * MMD_PLD >= MMD_TC * DMAX, "column-gradient staging aliases the coefficient tile");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int nb = (B + MMD_T - 1) / MMD_T, nbc = (B + MMD_TC - 1) / MMD_TC;
+    const int nrows = ROWS ? row_n : B;
+    const int nb = (nrows + MMD_T - 1) / MMD_T, nbc = (B + MMD_TC - 1) / MMD_TC;
     constexpr int CPR = MMD_T / MMD_TC;        // column chunks per row block
     const int Jend = min(nbc, ((int)blockIdx.y + 1) * JR);
-    const int Jbeg = max((int)blockIdx.y * JR, (int)blockIdx.x * 4 * CPR);
+    const int Jbeg = ROWS ? (int)blockIdx.y * JR : max((int)blockIdx.y * JR, (int)blockIdx.x * 4 * CPR);
     const int I = blockIdx.x * 4 + w;
-    const int i = I * MMD_T + lane;
-    const bool act = i < B;
-    // row gradients go to the slab of this column range (slab 0 collects the column gradients)
-    float* gslab = grad ? grad + (1 + (long long)blockIdx.y) * slab_stride + (long long)i * D : nullptr;
+    const int il = I * MMD_T + lane;           // row within the launch's row range
+    const int i = (ROWS ? row_lo : 0) + il;
+    const bool act = il < nrows;
+    // row gradients go to the slab of this column range (symmetric form: slab 0 collects the column gradients)
+    float* gslab = grad ? grad + ((ROWS ? 0 : 1) + (long long)blockIdx.y) * slab_stride + (long long)il * D : nullptr;
     if (Jbeg >= Jend) {                        // every tile of this workgroup lies below the diagonal
         if (threadIdx.x == 0) loss_part[blockIdx.y * gridDim.x + blockIdx.x] = 0.0;
         if (act && gslab)
@@ -319,8 +327,8 @@ __global__ __launch_bounds__(256) void mmd_small_kernel(const float* __restrict_
         const unsigned long long ends =
             __ballot(lane < nj && (lane == nj - 1 || cj[min(lane + 1, MMD_TC - 1)] != cj[min(lane, MMD_TC - 1)]));
         const int Ij = J / CPR;                // row block the chunk's columns belong to
-        const bool mine = I <= Ij && I < nb;   // wave-uniform
-        const bool diag = I == Ij;
+        const bool mine = (ROWS || I <= Ij) && I < nb;   // wave-uniform
+        const bool diag = ROWS || I == Ij;
         const bool park = mine && !diag && grad != nullptr;
         float gj[KH];
 #pragma unroll
@@ -393,7 +401,7 @@ __global__ __launch_bounds__(256) void mmd_small_kernel(const float* __restrict_
                 }
             }
         }
-        if (grad != nullptr) {
+        if (!ROWS && grad != nullptr) {
             // column gradients of the four waves: staged in each wave's own (now dead) coefficient tile, summed, added
 #pragma unroll
             for (int q = 0; q < KH; ++q) {
@@ -424,21 +432,23 @@ __global__ __launch_bounds__(256) void mmd_generic_kernel(const float* __restric
                                                           const int32_t* __restrict__ cond, int B, int D, int C,
                                                           const float* __restrict__ Wt, int jchunk,
                                                           double* __restrict__ loss_part,
-                                                          float* __restrict__ grad_slabs, long long slab_stride) {
+                                                          float* __restrict__ grad_slabs, long long slab_stride,
+                                                          int row_lo, int row_end) {
     extern __shared__ float sm[];          // yi [16][D] | yj [16][D] | coef [16][17]
     float* yi = sm;
     float* yj = sm + 16 * D;
     float* coef = sm + 32 * D;
     __shared__ double redd[16];
     const int t = threadIdx.x, ti = t >> 4, tj = t & 15;
-    const int i0 = blockIdx.x * 16;
+    // rows [row_lo, row_end) against all columns: the whole minibatch, or one rank's row block of the gathered one
+    const int i0 = row_lo + blockIdx.x * 16;
     const int jbeg = blockIdx.y * jchunk, jend = min(B, jbeg + jchunk);
     for (int q = t; q < 16 * D; q += 256) {
         const int r = q / D, k = q - r * D;
-        yi[q] = (i0 + r < B) ? y[(long long)(i0 + r) * ldy + k] : 0.f;
+        yi[q] = (i0 + r < row_end) ? y[(long long)(i0 + r) * ldy + k] : 0.f;
     }
     const int gi = i0 + ti;
-    const int ci = gi < B ? cond[gi] : -1;
+    const int ci = gi < row_end ? cond[gi] : -1;
     // gradient accumulators: thread owns row ti (of 16) and features k = tj + 16*m
     constexpr int MAXM = 64;               // D <= 1024
     float gacc[MAXM];
@@ -459,7 +469,7 @@ __global__ __launch_bounds__(256) void mmd_generic_kernel(const float* __restric
             d2 = fmaf(d, d, d2);
         }
         float cf = 0.f;
-        if (gi < B && gj < jend && ci >= 0 && ci < C) {
+        if (gi < row_end && gj < jend && ci >= 0 && ci < C) {
             const int c2 = cond[gj];
             const float w = (c2 >= 0 && c2 < C) ? Wt[(long long)ci * C + c2] : 0.f;
             float K, Kp;
@@ -483,8 +493,8 @@ __global__ __launch_bounds__(256) void mmd_generic_kernel(const float* __restric
     }
     const double tot = block_sum_d((double)lsum, redd);
     if (t == 0) loss_part[blockIdx.y * gridDim.x + blockIdx.x] = tot;
-    if (gi < B && grad_slabs) {
-        float* g = grad_slabs + blockIdx.y * slab_stride + (long long)gi * D;
+    if (gi < row_end && grad_slabs) {
+        float* g = grad_slabs + blockIdx.y * slab_stride + (long long)(gi - row_lo) * D;
 #pragma unroll
         for (int m = 0; m < MAXM; ++m) {
             const int k = tj + 16 * m;
@@ -546,11 +556,11 @@ extern "C" int sca_mmd_fwd_bwd(const float* feat, int ld, const int32_t* cond, i
         const int nb = (B + MMD_T - 1) / MMD_T, nbc = (B + MMD_TC - 1) / MMD_TC, jr = mmd_small_jr(B);
         dim3 grid((nb + 3) / 4, (nbc + jr - 1) / jr);
         if (D == 10)        // the default latent width: exact-size instantiation, all k < D guards fold away
-            hipLaunchKernelGGL((mmd_small_kernel<10>), grid, dim3(256), 0, st, feat, ld, cond, B, D, C, Wt, loss_part,
-                               grad_slabs, slab_stride, jr);
+            hipLaunchKernelGGL((mmd_small_kernel<10, false>), grid, dim3(256), 0, st, feat, ld, cond, B, D, C, Wt,
+                               loss_part, grad_slabs, slab_stride, jr, 0, B);
         else
-            hipLaunchKernelGGL((mmd_small_kernel<16>), grid, dim3(256), 0, st, feat, ld, cond, B, D, C, Wt, loss_part,
-                               grad_slabs, slab_stride, jr);
+            hipLaunchKernelGGL((mmd_small_kernel<16, false>), grid, dim3(256), 0, st, feat, ld, cond, B, D, C, Wt,
+                               loss_part, grad_slabs, slab_stride, jr, 0, B);
     } else {
         const int jt = (B + 15) / 16;
         const int jchunk = ((jt + ns - 1) / ns) * 16;
@@ -559,7 +569,74 @@ extern "C" int sca_mmd_fwd_bwd(const float* feat, int ld, const int32_t* cond, i
         if (shm > 48 * 1024)
             hipFuncSetAttribute((const void*)mmd_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
         hipLaunchKernelGGL(mmd_generic_kernel, grid, dim3(256), shm, st, feat, ld, cond, B, D, C, Wt, jchunk, loss_part,
-                           grad_slabs, slab_stride);
+                           grad_slabs, slab_stride, 0, B);
+    }
+    SCA_CHECK_LAUNCH();
+    return 0;
+}
+
+// ---- row-block form (data-parallel MMD over the all-gathered minibatch) ----------------------------------------
+// Column chunks per workgroup: about 1024 workgroups over ceil(row_n / 256) x column ranges.
+static int mmd_rows_jr(int B, int row_n) {
+    const long long nb = (row_n + MMD_T - 1) / MMD_T, nbc = (B + MMD_TC - 1) / MMD_TC;
+    long long jr = ((nb + 3) / 4) * nbc / 1024;
+    if (jr < 1) jr = 1;
+    if (jr > 32) jr = 32;
+    return (int)jr;
+}
+extern "C" int sca_mmd_rows_num_slabs(int B, int row_n, int D) {
+    if (B <= 0 || row_n <= 0) return 0;
+    if (D <= 16) {
+        const int nbc = (B + MMD_TC - 1) / MMD_TC, jr = mmd_rows_jr(B, row_n);
+        return (nbc + jr - 1) / jr;
+    }
+    const int itiles = (row_n + 15) / 16, jt = (B + 15) / 16;
+    int chunks = (512 + itiles - 1) / itiles;
+    if (chunks > jt) chunks = jt;
+    return chunks < 1 ? 1 : chunks;
+}
+extern "C" int sca_mmd_rows_num_partials(int B, int row_n, int D) {
+    if (B <= 0 || row_n <= 0) return 0;
+    const int ns = sca_mmd_rows_num_slabs(B, row_n, D);
+    if (D <= 16) return (((row_n + MMD_T - 1) / MMD_T + 3) / 4) * ns;
+    return ns * ((row_n + 15) / 16);
+}
+
+// Rows [row_lo, row_lo + row_n) of the gathered minibatch `feat` [B][ld] against all B columns.  The weight table is
+// built from ALL B conditions (rows with a condition outside [0, C) - padding - are ignored), so
+//   sum over the ranks' row blocks of loss_part = the MMD of the whole minibatch, and
+//   grad_slabs (sca_mmd_rows_num_slabs x [row_n][D], slab_stride elements apart, summed by the consumer) = d mmd / d
+//   feat for the block's rows.  `beta` scales both linearly (a caller folds n_global / n_local in there so that a
+//   gradient all-reduce weighted by n_local / n_global adds the MMD term with weight 1).
+extern "C" int sca_mmd_rows_fwd_bwd(const float* feat, int ld, const int32_t* cond, int B, int D, int C, int boundary,
+                                    float beta, float* Wt, int32_t* counts, int row_lo, int row_n, double* loss_part,
+                                    float* grad_slabs, long long slab_stride, void* stream) {
+    if (B <= 0 || C <= 0 || row_n <= 0) return 0;
+    if (C > 4096 || D > 1024) return -2;
+    if (row_lo < 0 || (long long)row_lo + row_n > B) return -1;
+    if (grad_slabs && slab_stride < (long long)row_n * D) return -1;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(mmd_prepare_kernel, dim3(1), dim3(256), 2 * C * sizeof(int), st, cond, B, C, boundary, beta, Wt,
+                       counts, (float*)nullptr, 0LL);
+    const int ns = sca_mmd_rows_num_slabs(B, row_n, D);
+    if (D <= 16) {
+        const int nb = (row_n + MMD_T - 1) / MMD_T, jr = mmd_rows_jr(B, row_n);
+        dim3 grid((nb + 3) / 4, ns);
+        if (D == 10)
+            hipLaunchKernelGGL((mmd_small_kernel<10, true>), grid, dim3(256), 0, st, feat, ld, cond, B, D, C, Wt,
+                               loss_part, grad_slabs, slab_stride, jr, row_lo, row_n);
+        else
+            hipLaunchKernelGGL((mmd_small_kernel<16, true>), grid, dim3(256), 0, st, feat, ld, cond, B, D, C, Wt,
+                               loss_part, grad_slabs, slab_stride, jr, row_lo, row_n);
+    } else {
+        const int jt = (B + 15) / 16;
+        const int jchunk = ((jt + ns - 1) / ns) * 16;
+        dim3 grid((row_n + 15) / 16, ns);
+        const size_t shm = (size_t)(32 * D + 16 * 17) * sizeof(float);
+        if (shm > 48 * 1024)
+            hipFuncSetAttribute((const void*)mmd_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+        hipLaunchKernelGGL(mmd_generic_kernel, grid, dim3(256), shm, st, feat, ld, cond, B, D, C, Wt, jchunk, loss_part,
+                           grad_slabs, slab_stride, row_lo, row_lo + row_n);
     }
     SCA_CHECK_LAUNCH();
     return 0;

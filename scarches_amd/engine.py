@@ -1239,12 +1239,11 @@ class CVAEEngine:
         b = self._dp_ws.get(key)
         if b is None:
             dev, Bg = self.device, self._dp["world"] * n_max
-            ns = self.lib.sca_mmd_num_slabs(Bg, Dm)
+            ns = self.lib.sca_mmd_rows_num_slabs(Bg, n_max, Dm)
             b = dict(zpad=torch.zeros(n_max, Dm, device=dev),
                      cpad=torch.full((n_max,), -1, dtype=torch.int32, device=dev),
                      zall=torch.empty(Bg, Dm, device=dev), call=torch.empty(Bg, dtype=torch.int32, device=dev),
-                     slabs=torch.empty(max(1, ns) * Bg * Dm, device=dev), ns=ns)
-            b["g1"] = b["slabs"][:Bg * Dm].view(Bg, Dm) if ns == 1 else torch.empty(Bg, Dm, device=dev)
+                     slabs=torch.empty(max(1, ns) * n_max * Dm, device=dev))   # grown for ragged slices if needed
             self._dp_ws[key] = b
         return b
 
@@ -1267,10 +1266,6 @@ class CVAEEngine:
                 cp[:B].copy_(cond_t.view(-1)[:B])
             self._dp_gather(b["zall"], zp)
             self._dp_gather(b["call"], cp)
-
-    def _dp_take_rows(self, b, B, Dm, lo, scale, stream):
-        with torch.cuda.stream(stream):
-            torch.mul(b["g1"][lo:lo + B], scale, out=self.ws["mmd_g1"].view(-1)[:B * Dm].view(B, Dm))
 
     def dp_idle_step(self, n_global):
         """A rank whose slice of a (tiny, last) minibatch is empty still takes part in the step's all-gathers."""
@@ -1299,21 +1294,30 @@ class CVAEEngine:
         b = self._dp_bufs(n_max, Dm)
         stream = self.aux if (self.overlap and sa == self.aux.cuda_stream) else torch.cuda.current_stream(self.device)
         self._call(self._dp_stage_gather, b, feat, cond_t, B, Dm, stream)
-        _lib.check(L.sca_mmd_fwd_bwd(b["zall"].data_ptr(), Dm, b["call"].data_ptr(), Bg, Dm, C, bnd, self.beta,
-                                     ws["Wt"].data_ptr(), ws["counts"].data_ptr(), ws["mmd_part"].data_ptr(),
-                                     b["slabs"].data_ptr() if compute_grad else None, Bg * Dm, sa), "mmd[dp]")
-        if compute_grad:
-            if b["ns"] > 1:
-                _lib.check(L.sca_splitk_reduce(b["slabs"].data_ptr(), b["ns"], Bg * Dm, b["g1"].data_ptr(), Bg * Dm, sa),
-                           "mmd_reduce[dp]")
-            self._call(self._dp_take_rows, b, B, Dm, d["rank"] * n_max, n_global / float(B), stream)
+        # this rank's row block against all columns of the gathered minibatch.  beta carries n_global / n_local: the
+        # logged MMD is then (n_global / n_local) x the block's share and the gradient rows are scaled alike, so the
+        # n_local / n_global-weighted all-reduces (gradients per step, log sums per epoch) give the whole-minibatch
+        # MMD and its gradient with weight 1.
+        ns = L.sca_mmd_rows_num_slabs(Bg, B, Dm)
+        if compute_grad and ns > 1 and b["slabs"].numel() < ns * B * Dm:      # eager step: allocation is fine here
+            b["slabs"] = torch.empty(ns * B * Dm, device=self.device)
+        g_out = ws["mmd_g1"].data_ptr() if ns == 1 else b["slabs"].data_ptr()
+        _lib.check(L.sca_mmd_rows_fwd_bwd(b["zall"].data_ptr(), Dm, b["call"].data_ptr(), Bg, Dm, C, bnd,
+                                          self.beta * (n_global / float(B)), ws["Wt"].data_ptr(),
+                                          ws["counts"].data_ptr(), d["rank"] * n_max, B, ws["mmd_part"].data_ptr(),
+                                          g_out if compute_grad else None, B * Dm, sa), "mmd_rows[dp]")
+        if compute_grad and ns > 1:
+            _lib.check(L.sca_splitk_reduce(b["slabs"].data_ptr(), ns, B * Dm, ws["mmd_g1"].data_ptr(), B * Dm, sa),
+                       "mmd_reduce[dp]")
 
     def _mmd_partials(self, B, Dm):
         """Number of loss partials the MMD launch of this step writes (ws['mmd_part'] is grown to hold them)."""
         if self._dp_exact():
             d = self._dp
-            B = d["world"] * -(-int(self._dp_n_global or B * d["world"]) // d["world"])
-        n = self.lib.sca_mmd_num_partials(B, Dm)
+            Bg = d["world"] * -(-int(self._dp_n_global or B * d["world"]) // d["world"])
+            n = self.lib.sca_mmd_rows_num_partials(Bg, B, Dm)
+        else:
+            n = self.lib.sca_mmd_num_partials(B, Dm)
         if self.ws["mmd_part"].numel() < n:
             self.ws["mmd_part"] = torch.zeros(n, dtype=torch.float64, device=self.device)
         return n

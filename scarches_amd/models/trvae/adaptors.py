@@ -94,7 +94,8 @@ def attach_adaptors(trvae_model: TRVAE, adaptors: list, only_new: bool = False):
         adaptor._validate_params(trvae_model.adata.var_names, init_params)
         adpt_conditions.append(adaptor.condition)
         for k, p in adaptor.cond_params.items():
-            cond_params[k] = p.clone() if k not in cond_params else torch.cat([cond_params[k], p], dim=-1)
+            p = p.detach().to("cpu", copy=True)      # adaptors may come from disk (host) or from a model in HBM
+            cond_params[k] = p if k not in cond_params else torch.cat([cond_params[k], p], dim=-1)
 
     conditions = init_params['conditions']
     inds_exist, inds_old, inds_new = [], [], []

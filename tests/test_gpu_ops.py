@@ -153,6 +153,55 @@ def test_mmd_golden(lib, key):
         assert rel_err(grad, z[f"mmd_{key}_grad"]) < 5e-5
 
 
+@pytest.mark.parametrize("key", list("abcde"))
+def test_mmd_row_blocks_golden(lib, key):
+    """sca_mmd_rows_fwd_bwd (row block x all columns, the data-parallel form): ragged row blocks of the golden
+    minibatches - incl. an empty one and padding rows with condition -1 between the blocks - add up to the reference's
+    MMD value, and every block's gradient rows are the reference's gradient rows."""
+    from scarches_amd import _lib
+    from oracle import cvae_oracle as O
+    z = np.load(GOLDEN + "/ops.npz")
+    c = json.loads(str(z[f"mmd_{key}_cfg"]))
+    y, lab = z[f"mmd_{key}_y"], z[f"mmd_{key}_c"]
+    B, D, C = y.shape[0], y.shape[1], c["C"]
+    cuts = [0, B // 3, B // 3, B - 1, B]                    # blocks of B/3, 0, ~2B/3 - 1 and 1 rows
+    pad = 3                                                  # padding rows after every block
+    ypad, lpad, starts = [], [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        starts.append(sum(len(a) for a in ypad))
+        ypad += [y[lo:hi], np.full((pad, D), 7.5, dtype=np.float32)]
+        lpad += [lab[lo:hi].astype(np.int32), np.full(pad, -1, dtype=np.int32)]
+    yp, lp = dev(np.concatenate(ypad)), dev(np.concatenate(lpad), torch.int32)
+    Bg = yp.shape[0]
+    Wt = torch.empty(C * C, device="cuda")
+    bnd = -1 if c["boundary"] is None else c["boundary"]
+    val, ref_grad = 0.0, z[f"mmd_{key}_grad"]
+    for (lo, hi), s0 in zip(zip(cuts[:-1], cuts[1:]), starts):
+        n = hi - lo
+        ns, npart = lib.sca_mmd_rows_num_slabs(Bg, n, D), lib.sca_mmd_rows_num_partials(Bg, n, D)
+        if n == 0:
+            assert ns == 0 and npart == 0
+            assert lib.sca_mmd_rows_fwd_bwd(yp.data_ptr(), D, lp.data_ptr(), Bg, D, C, bnd, c["beta"], Wt.data_ptr(),
+                                            None, s0, 0, None, None, 0, st()) == 0
+            continue
+        part = torch.full((npart,), float("nan"), dtype=torch.float64, device="cuda")
+        slabs = torch.full((ns, n, D), float("nan"), device="cuda")
+        _lib.check(lib.sca_mmd_rows_fwd_bwd(yp.data_ptr(), D, lp.data_ptr(), Bg, D, C, bnd, c["beta"], Wt.data_ptr(),
+                                            None, s0, n, part.data_ptr(), slabs.data_ptr(), n * D, st()), "mmd_rows")
+        torch.cuda.synchronize()
+        val += part.sum().item()
+        g = slabs.sum(0).cpu().numpy()
+        if float(z[f"mmd_{key}_val"]) != 0:
+            assert np.abs(g - ref_grad[lo:hi]).max() <= 5e-5 * np.abs(ref_grad).max(), (key, lo, hi)
+    val64 = O.mmd_loss(torch.tensor(y).double(), torch.tensor(lab), C, c["beta"], c["boundary"]).item()
+    assert abs(val - val64) <= 1e-5 * abs(val64) + 1e-6
+    # argument checks: a row range outside the minibatch, a slab stride shorter than the block
+    assert lib.sca_mmd_rows_fwd_bwd(yp.data_ptr(), D, lp.data_ptr(), Bg, D, C, bnd, 1.0, Wt.data_ptr(), None, Bg - 1, 2,
+                                    None, None, 0, st()) == -1
+    assert lib.sca_mmd_rows_fwd_bwd(yp.data_ptr(), D, lp.data_ptr(), Bg, D, C, bnd, 1.0, Wt.data_ptr(), None, 0, 2,
+                                    Wt.data_ptr(), Wt.data_ptr(), D, st()) == -1
+
+
 def test_nb_rows_against_oracle(lib):
     """softmax + NB rows kernel on random logits: per-row ll, dlogits, dtheta, dbias vs the f64 oracle."""
     from scarches_amd import _lib
