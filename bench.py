@@ -239,7 +239,7 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            t = torch.tensor([dt], device="cpu" if rehearsal else dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = t.item()
         return dt

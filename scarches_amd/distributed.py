@@ -15,6 +15,35 @@ def is_dist() -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def _host_staged(t: torch.Tensor) -> bool:
+    """gloo is the CPU backend (tests, one-GPU rehearsals of the multi-rank path): device tensors go through the host
+    explicitly instead of through ProcessGroupGloo's own device path (worker-thread copies on private streams), which
+    hung intermittently with two ranks sharing one GPU.  RCCL ("nccl") takes device tensors as they are."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
+    """In-place sum over ranks on the tensor's current stream semantics (RCCL) or staged through the host (gloo)."""
+    if _host_staged(t):
+        h = t.detach().cpu()            # synchronises with the work queued on the current stream
+        dist.all_reduce(h, op=dist.ReduceOp.SUM)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def all_gather_rows_(out: torch.Tensor, local: torch.Tensor) -> torch.Tensor:
+    """out[world * n, ...] <- the ranks' equally sized `local[n, ...]` blocks in rank order."""
+    if _host_staged(local):
+        ho, hl = torch.empty(out.shape, dtype=out.dtype), local.detach().cpu()
+        dist.all_gather_into_tensor(ho, hl)
+        out.copy_(ho)
+    else:
+        dist.all_gather_into_tensor(out, local)
+    return out
+
+
 def allreduce_mean_(flat: torch.Tensor, world: int | None = None, weight: float | None = None) -> torch.Tensor:
     """In-place all-reduce of the flat gradient buffer (the whole model is one bucket).
 
@@ -27,9 +56,8 @@ def allreduce_mean_(flat: torch.Tensor, world: int | None = None, weight: float 
         return flat
     if weight is not None:
         flat.mul_(float(weight))
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        return flat
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        return all_reduce_sum_(flat)
+    all_reduce_sum_(flat)
     flat.mul_(1.0 / world)
     return flat
 
@@ -44,7 +72,7 @@ def local_slice(ids: torch.Tensor, rank: int, world: int) -> torch.Tensor:
 
 def allreduce_sum_(t: torch.Tensor) -> torch.Tensor:
     if is_dist():
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        all_reduce_sum_(t)
     return t
 
 

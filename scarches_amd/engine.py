@@ -1251,8 +1251,8 @@ class CVAEEngine:
         if self._dp["gather"] is not None:
             self._dp["gather"](out, local)
         else:
-            import torch.distributed as dist
-            dist.all_gather_into_tensor(out, local)
+            from . import distributed as sdist
+            sdist.all_gather_rows_(out, local)
 
     def _dp_stage_gather(self, b, feat, cond_t, B, Dm, stream):
         """Pad this rank's rows to n_max (condition -1 = ignored by the kernels) and all-gather rows + conditions."""
@@ -1337,18 +1337,16 @@ class CVAEEngine:
                      against 0.37 ms eager) - "auto" for B <= 4096 (0.46 ms at B=4096, where the plan is bimodal);
           * False  : launched eagerly through the normal Python path."""
         if use_graph == "auto":
-            # world > 1: the gradient all-reduce is a host call between the two halves of the step.  Graph replays
-            # around it hung in the two-rank rehearsal of bench.py (gloo, both ranks on one GPU) where the plan and
-            # the eager step run, so "auto" only picks the graph for the single-process step.
-            use_graph = True if (B <= 4096 and world == 1) else "plan"
+            # (world > 1: the gradient all-reduce is a host call between the two replayed halves of the step.  The
+            # intermittent hangs of bench.py's two-rank one-GPU rehearsal came from ProcessGroupGloo's device-tensor
+            # path, not from the launch mode: see distributed._host_staged.)
+            use_graph = True if B <= 4096 else "plan"
         dp_exact = world > 1 and self._dp_exact()
         if dp_exact:
             self._dp_n_global = int(n_global) if n_global is not None else B * world
             # The step holds two all-gathers in its middle: it is launched eagerly.  (Every rank must issue the same
             # collectives in the same order: a ragged last minibatch gives the ranks different local sizes - or none,
-            # dp_idle_step - so ranks would record plans at different steps, and recording runs the step twice.  A
-            # replayed plan with the gathers as host calls also hung in the two-rank rehearsal of bench.py over gloo,
-            # where the eager step runs; not understood, so not shipped.)
+            # dp_idle_step - so ranks would record plans at different steps, and recording runs the step twice.)
             use_graph = False
         if use_graph is False:
             self.begin_step(alpha_kl, lr, eps, clip)
