@@ -218,6 +218,30 @@ class scPoli(BaseMixin):
                             "weighted_distances": dist.cpu().numpy()}
         return results
 
+    def get_prototypes_info(self, prototype_set="labeled"):
+        """Prototype means as an AnnData-like table (X = [n_prototypes, latent_dim]) with `batch`, and per cell-type
+        key the prototype's name, predicted label and uncertainty (scpoli_model.py:605-664).  As upstream the name
+        column holds the prototype's index (its branch for true names tests `prototype_set == "l"`, never taken), and
+        an unknown `prototype_set` prints a message and returns None."""
+        import pandas as pd
+        from ...anndata_lite import CellData
+        if prototype_set == "labeled":
+            prototypes, batch_name = self.prototypes_labeled_["mean"], "prototype-Set Labeled"
+        elif prototype_set == "unlabeled":
+            prototypes, batch_name = self.prototypes_unlabeled_["mean"], "prototype-Set Unlabeled"
+        else:
+            print(f"Parameter 'prototype_set' has either to be 'labeled' for labeled prototype set or 'unlabeled' "
+                  f"for the unlabeled prototype set. But given value was {prototype_set}")
+            return None
+        prototypes = prototypes.detach().cpu().numpy()
+        obs = pd.DataFrame({"batch": np.array(prototypes.shape[0] * [batch_name])})
+        results = self.classify(prototypes, prototype=True)
+        for key in self.cell_type_keys_:
+            obs[key] = np.array([f"{i}" for i in range(prototypes.shape[0])])
+            obs[key + "_pred"] = results[key]["preds"]
+            obs[key + "_uncert"] = results[key]["uncert"]
+        return CellData(prototypes, obs, var_names=[f"{i}" for i in range(prototypes.shape[1])])
+
     def add_new_cell_type(self, cell_type_name, obs_key, prototypes, x=None, c=None):
         """Promote a set of unlabeled prototypes to a new labeled cell type `cell_type_name` at hierarchy `obs_key`."""
         if x is None and c is None:
