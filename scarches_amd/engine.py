@@ -375,12 +375,17 @@ class CVAEEngine:
         for ly in self.enc + self.dec:
             ws[ly.tag + ".da"] = torch.empty(B, ly.n_out, dtype=f32, device=dev)
         Dm = Z if (self.mmd_on == "z" or xp) else self.dec[0].n_out
-        self._mmd_ns = L.sca_mmd_num_slabs(B, Dm)
-        ws["mmd_g"] = torch.empty(max(1, self._mmd_ns) * B * Dm, dtype=f32, device=dev)
-        ws["mmd_part"] = torch.zeros(max(1, L.sca_mmd_num_partials(B, Dm)), dtype=torch.float64, device=dev)
-        # one slab (small-D kernel: atomically accumulated) needs no reduction: the consumers read it in place
-        ws["mmd_g1"] = (ws["mmd_g"][:B * Dm].view(B, Dm) if self._mmd_ns == 1
-                        else torch.empty(B, Dm, dtype=f32, device=dev))
+        # The slab / partial counts of the MMD kernels are not monotone in the batch size (fewer column chunks per
+        # workgroup at smaller B): size for the worst case over every B' <= B, so that a ragged last minibatch or a
+        # validation batch never outgrows buffers whose addresses recorded launch plans hold.  The counts only change
+        # at multiples of 16 rows.
+        g_need, p_need = 1, 1
+        for b in list(range(16, B, 16)) + [B]:
+            g_need = max(g_need, L.sca_mmd_num_slabs(b, Dm) * b * Dm)
+            p_need = max(p_need, L.sca_mmd_num_partials(b, Dm))
+        ws["mmd_g"] = torch.empty(g_need, dtype=f32, device=dev)
+        ws["mmd_part"] = torch.zeros(p_need, dtype=torch.float64, device=dev)
+        ws["mmd_g1"] = torch.empty(B, Dm, dtype=f32, device=dev)      # the summed gradient the backward pass reads
         self._sbh = torch.empty(B * Hmax, dtype=f32, device=dev)
         ws["Wt"] = torch.empty(C * C, dtype=f32, device=dev)
         ws["counts"] = torch.empty(C, dtype=torch.int32, device=dev)
@@ -1280,11 +1285,15 @@ class CVAEEngine:
         L, ws, C = self.lib, self.ws, self.C
         bnd = -1 if self.boundary is None else int(self.boundary)
         if not self._dp_exact():
+            ns = L.sca_mmd_num_slabs(B, Dm)
+            if ns * B * Dm > ws["mmd_g"].numel():
+                raise RuntimeError("MMD gradient slabs exceed the workspace (%d x %d x %d)" % (ns, B, Dm))
+            g_out = ws["mmd_g1"] if ns == 1 else ws["mmd_g"]          # a single slab is the gradient itself
             _lib.check(L.sca_mmd_fwd_bwd(feat.data_ptr(), Dm, cond_p, B, Dm, C, bnd, self.beta,
                                          ws["Wt"].data_ptr(), ws["counts"].data_ptr(), ws["mmd_part"].data_ptr(),
-                                         ws["mmd_g"].data_ptr() if compute_grad else None, B * Dm, sa), "mmd")
-            if compute_grad and L.sca_mmd_num_slabs(B, Dm) > 1:      # gradient slabs summed off the critical path
-                _lib.check(L.sca_splitk_reduce(ws["mmd_g"].data_ptr(), L.sca_mmd_num_slabs(B, Dm), B * Dm,
+                                         g_out.data_ptr() if compute_grad else None, B * Dm, sa), "mmd")
+            if compute_grad and ns > 1:                                # gradient slabs summed off the critical path
+                _lib.check(L.sca_splitk_reduce(ws["mmd_g"].data_ptr(), ns, B * Dm,
                                                ws["mmd_g1"].data_ptr(), B * Dm, sa), "mmd_reduce")
             return
         d = self._dp

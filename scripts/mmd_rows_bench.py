@@ -26,7 +26,7 @@ def main():
     D, C = 10, 20
     st = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device="cuda").manual_seed(0)
-    for world, n in [(2, 1024), (8, 128), (8, 1024), (2, 8192), (8, 8192)]:
+    for world, n in [(1, 1024), (1, 4096), (1, 8192), (1, 16384), (2, 1024), (8, 128), (8, 1024), (2, 8192), (8, 8192)]:
         Bg = world * n
         z = torch.randn(Bg, D, device="cuda", generator=g)
         c = torch.sort(torch.randint(0, C, (Bg,), device="cuda", generator=g).to(torch.int32))[0].contiguous()
@@ -41,7 +41,7 @@ def main():
         partr = torch.zeros(npr, dtype=torch.float64, device="cuda")
         slabr = torch.empty(nsr * n * D, device="cuda")
         rows = timeit(lambda: L.sca_mmd_rows_fwd_bwd(z.data_ptr(), D, c.data_ptr(), Bg, D, C, -1, 1.0, Wt.data_ptr(),
-                                                     None, n, n, partr.data_ptr(), slabr.data_ptr(), n * D, st))
+                                                     None, 0, n, partr.data_ptr(), slabr.data_ptr(), n * D, st))
         v = 0.0
         for r in range(world):
             L.sca_mmd_rows_fwd_bwd(z.data_ptr(), D, c.data_ptr(), Bg, D, C, -1, 1.0, Wt.data_ptr(), None, r * n, n,

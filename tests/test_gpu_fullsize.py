@@ -228,3 +228,35 @@ def test_fused_vs_unfused_odd_shapes(cfg):
     la, lb = a.losses.cpu().numpy(), b.losses.cpu().numpy()
     assert np.all(np.isfinite(la)) and np.all(np.abs(la[:3] - lb[:3]) <= 1e-5 * np.abs(lb[:3]) + 1e-7), (la, lb)
     assert_grads_close(grads(a), grads(b))
+
+
+@pytest.mark.parametrize("n_small", [6000, 4000, 20])
+def test_smaller_minibatch_after_the_full_one(data, n_small):
+    """A ragged last minibatch / validation batch on an engine whose workspaces were sized for 8192 cells: the MMD
+    kernels use MORE gradient slabs and loss partials at some smaller batch sizes (fewer column chunks per workgroup),
+    so the workspaces are sized for the worst case over all sizes - the step must equal that of a fresh engine which
+    only ever saw the small batch, and a step at the full size afterwards must be unchanged."""
+    L = __import__("scarches_amd._lib", fromlist=["load"]).load()
+    sel = torch.sort(torch.randperm(B, device="cuda", generator=torch.Generator(device="cuda").manual_seed(n_small))
+                     [:n_small])[0]
+    rows, cond = data["rows"][sel].contiguous(), data["cond"][sel].contiguous()
+    eps_big, eps = torch.randn(B, Z, device="cuda"), torch.randn(n_small, Z, device="cuda")
+    a, b = make_engine(data, dr_rate=0.0), make_engine(data, dr_rate=0.0)
+    a.begin_step(alpha_kl=0.5, lr=1e-3)
+    a.forward_backward(data["rows"], data["cond"], B, eps=eps_big)
+    torch.cuda.synchronize()
+    l_big, g_big = a.losses.cpu().numpy().copy(), grads(a)
+    assert L.sca_mmd_num_slabs(n_small, Z) * n_small * Z <= a.ws["mmd_g"].numel()
+    assert L.sca_mmd_num_partials(n_small, Z) <= a.ws["mmd_part"].numel()
+    for e in (a, b):
+        e.begin_step(alpha_kl=0.5, lr=1e-3)
+        e.forward_backward(rows, cond, n_small, eps=eps)
+    torch.cuda.synchronize()
+    la, lb = a.losses.cpu().numpy(), b.losses.cpu().numpy()
+    assert np.all(np.abs(la[:3] - lb[:3]) <= 1e-5 * np.abs(lb[:3]) + 1e-7), (la, lb)
+    assert_grads_close(grads(a), grads(b))
+    a.begin_step(alpha_kl=0.5, lr=1e-3)
+    a.forward_backward(data["rows"], data["cond"], B, eps=eps_big)
+    torch.cuda.synchronize()
+    assert np.all(np.abs(a.losses.cpu().numpy()[:3] - l_big[:3]) <= 1e-6 * np.abs(l_big[:3]))
+    assert_grads_close(grads(a), g_big, rtol=1e-5)
