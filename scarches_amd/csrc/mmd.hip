@@ -596,10 +596,16 @@ extern "C" int sca_mmd_fwd_bwd(const float* feat, int ld, const int32_t* cond, i
 }
 
 // ---- row-block form (data-parallel MMD over the all-gathered minibatch) ----------------------------------------
-// Column chunks per workgroup: about 1024 workgroups over ceil(row_n / 256) x column ranges.
+// Column chunks per workgroup: about 4096 workgroups over ceil(row_n / 256) x column ranges, and at least two chunks
+// from 4096 columns on.  Short workgroups interleave better with the likelihood kernel that shares the chip with the
+// MMD inside the step (cfg2 step at B = 8192: 0.711 ms with 8 chunks = 1024 workgroups, 0.703 / 0.684 / 0.673 / 0.693
+// with 6 / 3 / 2 / 1; at B = 4096: 0.411 with 2, 0.423 with 1, 0.416 with 4; B = 2048: 1 and 2 equal).
 static int mmd_rows_jr(int B, int row_n) {
     const long long nb = (row_n + MMD_T - 1) / MMD_T, nbc = (B + MMD_TC - 1) / MMD_TC;
-    long long jr = ((nb + 3) / 4) * nbc / 1024;
+    long long jr = ((nb + 3) / 4) * nbc / 4096;
+    if (jr < 2 && nbc >= 128) jr = 2;
+    static const int jr_env = [] { const char* v = getenv("SCA_MMD_ROWS_JR"); return v ? atoi(v) : 0; }();
+    if (jr_env > 0) jr = jr_env;
     if (jr < 1) jr = 1;
     if (jr > 32) jr = 32;
     return (int)jr;
