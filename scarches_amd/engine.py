@@ -15,6 +15,8 @@ from collections import OrderedDict
 from typing import Dict, List, Optional
 
 import numpy as np
+import os
+
 import torch
 
 from . import _lib
@@ -57,6 +59,15 @@ class _RecordingLib:
                 return raw(*args)
         setattr(self, name, fn)
         return fn
+
+
+def _recon_rows_per_block(B):
+    """Rows a likelihood workgroup walks (theta gradients stay in registers across them): ~512 workgroups = two per
+    CU, at most 16 rows.  Measured inside the cfg2 step (scripts/ab_env.sh, ms/step): B=1024 0.305 / 0.287 / 0.293 with
+    1 / 2 / 4 rows, B=2048 0.326 / 0.313 / 0.335 with 2 / 4 / 8, B=4096 0.431 / 0.409 / 0.396 / 0.444 with 2 / 4 / 8 / 16,
+    B=8192 0.695 / 0.693 / 0.673 / 0.674 with 2 / 4 / 8 / 16.  SCA_RECON_RPB overrides it for A/B runs."""
+    v = os.environ.get("SCA_RECON_RPB")
+    return max(1, int(v)) if v else min(16, max(1, B // 512))
 
 
 class CVAEEngine:
@@ -719,7 +730,7 @@ class CVAEEngine:
         ev_side = self._flush() if self._aux_q else ev_z
         self._wait(self._ev_pro)
         # 6. reconstruction loss (+ gradient w.r.t. the logits, in place)
-        rpb = max(1, B // 1024)
+        rpb = _recon_rows_per_block(B)
         gob = self.g[self.out_b].data_ptr() if self.trainable[self.out_b] else None
         if self.recon == "mse":
             _lib.check(L.sca_mse_rows(ws["logits"].data_ptr(), G, ws["x"].data_ptr(), G, B, G, rpb,
@@ -978,7 +989,7 @@ class CVAEEngine:
         self._gemm(0, 0, h_last, Hd, P[self.out_w].data_ptr(), Hd, B, G, Hd, st, out=ws["logits"].data_ptr(), ldc=G,
                    bias=P[self.out_b].data_ptr(), force_s1=True)
         self._wait(self._ev_pro)
-        rpb = max(1, B // 1024)
+        rpb = _recon_rows_per_block(B)
         gob = self.g[self.out_b].data_ptr() if T[self.out_b] else None
         if self.recon == "mse":
             _lib.check(L.sca_mse_rows(ws["logits"].data_ptr(), G, ws["x"].data_ptr(), G, B, G, rpb,
@@ -1143,7 +1154,7 @@ class CVAEEngine:
                    out=ws["logits"].data_ptr(), ldc=G, force_s1=True)
         ev_side = self._flush()
         self._wait(self._ev_pro)
-        rpb = max(1, B // 1024)
+        rpb = _recon_rows_per_block(B)
         if self.recon == "mse":
             _lib.check(L.sca_mse_rows(ws["logits"].data_ptr(), G, ws["x"].data_ptr(), G, B, G, rpb,
                                       ws["row_ll"].data_ptr(), None, int(compute_grad), 0, cond_p, coff, st),
