@@ -523,11 +523,12 @@ extern "C" int sca_mmd_rows_fwd_bwd(const float* feat, int ld, const int32_t* co
                                     float* grad_slabs, long long slab_stride, void* stream);
 // Whole-minibatch MMD through the row-block instantiation (all ordered pairs, no transposed pass, no column atomics,
 // evenly loaded workgroups) instead of the symmetric one (half the exps, triangular load): faster alone up to
-// B = 8192 on MI355X (50 vs 62 us at 4096, 158 vs 187 at 8192, 538 vs 528 at 16384).
+// B = 8192 on MI355X (50 vs 62 us at 4096, 158 vs 187 at 8192, 498 vs 536 at 16384 with ~4096 workgroups) and inside
+// the cfg2 step up to the 16384 cells measured (1.126 -> 1.094 ms at 12288, 1.569 -> 1.492 at 16384).
 static bool mmd_full_as_rows(int B, int D) {
     // (inside the cfg2 step: 0.438 -> 0.411 ms at B = 4096, 0.735 -> 0.708 ms at B = 8192; SCA_MMD_ROWS_MAX=0 restores
     //  the symmetric kernel for A/B runs)
-    static const int bmax = [] { const char* v = getenv("SCA_MMD_ROWS_MAX"); return v ? atoi(v) : 8192; }();
+    static const int bmax = [] { const char* v = getenv("SCA_MMD_ROWS_MAX"); return v ? atoi(v) : 16384; }();
     return D <= 16 && B <= bmax;
 }
 
