@@ -262,10 +262,12 @@ __global__ __launch_bounds__(256) void mmd_small_kernel(const float* __restrict_
                                                         int row_lo, int row_n) {
     constexpr int KH = (DMAX + 1) / 2;        // features per half-wave in the transposed pass
     constexpr int ZS = ((KH + 1 + 3) / 4) * 4;                          // floats per (row, half) in the staged rows
-    __shared__ __attribute__((aligned(16))) float zis[4][MMD_T * 2 * ZS];
+    // (the row-block form has no transposed pass: its staging rows and coefficient tiles shrink to nothing, which
+    //  leaves the CU's LDS to the kernels that share the chip with it)
+    __shared__ __attribute__((aligned(16))) float zis[ROWS ? 1 : 4][ROWS ? 4 : MMD_T * 2 * ZS];
     __shared__ __attribute__((aligned(8))) float zj[MMD_TC * DMAX];
     __shared__ int cj[MMD_TC];
-    __shared__ float Pt[4][MMD_TC * MMD_PLD];  // per wave: coef tile [column][row]; later the wave's column gradients
+    __shared__ float Pt[ROWS ? 1 : 4][ROWS ? 1 : MMD_TC * MMD_PLD];  // per wave: coef tile [column][row]; later the wave's column gradients
     __shared__ double redd[16];
     static_assert(MMD_TC * MMD_PLD >= MMD_TC * DMAX, "column-gradient staging aliases the coefficient tile");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -302,6 +304,7 @@ __global__ __launch_bounds__(256) void mmd_small_kernel(const float* __restrict_
     }
     // staged rows for the transposed pass: [i][half][ZS] = {1, z_i[half*KH .. half*KH + KH)} (the leading 1 makes
     // sum_i coef part of the same packed FMA chain)
+    if constexpr (!ROWS)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(256) void mmd_small_kernel(const float* __restrict_
                     const v2f cc = {coef, coef};
 #pragma unroll
                     for (int k = 0; k < DP; ++k) gr2[k] = pk_fma(cc, diff[u][k], gr2[k]);
-                    if (park) Pt[w][(jj + u) * MMD_PLD + lane] = coef;
+                    if constexpr (!ROWS) { if (park) Pt[w][(jj + u) * MMD_PLD + lane] = coef; }
                 }
             };
             int jj = 0;
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(256) void mmd_small_kernel(const float* __restrict_
                 for (; jj + 4 <= je; jj += 4) columns(std::integral_constant<int, 4>{}, jj);
                 for (; jj < je; ++jj) columns(std::integral_constant<int, 1>{}, jj);
             }
-            if (park) {
+            if constexpr (!ROWS) if (park) {
                 // roles swapped: lane = (column jp, feature half kh); rows of this wave come from LDS
                 v2f acc2[ZS / 2];                  // (sum coef, acc_0), (acc_1, acc_2), ...
 #pragma unroll
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(256) void mmd_small_kernel(const float* __restrict_
                 }
             }
         }
-        if (!ROWS && grad != nullptr) {
+        if constexpr (!ROWS) if (grad != nullptr) {
             // column gradients of the four waves: staged in each wave's own (now dead) coefficient tile, summed, added
 #pragma unroll
             for (int q = 0; q < KH; ++q) {
