@@ -131,10 +131,12 @@ int sca_mmd_rows_fwd_bwd(const float* feat, int ld, const int32_t* cond, int B, 
                          long long slab_stride, void* stream);
 
 /* ---- optimiser / bookkeeping ---------------------------------------------------------------------------------
- * hyper (device, float[8]): [0] alpha_kl  [1] lr  [2] 1-beta1^t  [3] sqrt(1-beta2^t)  [4] adam eps  [5] clip value.
+ * hyper (device, float[8]): [0] alpha_kl  [1] lr  [2] 1-beta1^t  [3] sqrt(1-beta2^t)  [4] adam eps  [5] clip value
+ * [6] weight of this minibatch in the epoch-log accumulators (1; n_local / n_global on a data-parallel rank).
  * sca_adam_step: torch.optim.Adam semantics (trainers/trvae/trainer.py:221-223, clip: :277-278) on a flat range.
  * sca_finalize_losses: losses[0..3] = recon (= recon_sign * sum(row_recon)/B), kl, mmd, recon + alpha*kl + mmd
- * (trainers/trvae/unsupervised.py:62-70); accum[0..3] += those, accum[4] += 1 (per-epoch log means without syncs). */
+ * (trainers/trvae/unsupervised.py:62-70); accum[0..3] += hyper[6] * those, accum[4] += hyper[6] (per-epoch log means
+ * without host syncs; trainers/trvae/trainer.py:284-285). */
 int sca_adam_step(float* p, const float* g, float* m, float* v, long long n, const float* hyper, float beta1,
                   float beta2, float weight_decay, void* stream);
 /* sca_begin_step: hyper[0..5] <- the per-step scalars (values of trainer.py:193-209 annealing, param_groups lr, Adam

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
-// losses[0..3] = recon, kl, mmd, total (= recon + alpha*kl + mmd);  accum[0..3] += the same; accum[4] += 1.
+// losses[0..3] = recon, kl, mmd, total (= recon + alpha*kl + mmd);  accum[0..3] += w * the same; accum[4] += w, w = hyper[6].
 __global__ __launch_bounds__(256) void finalize_losses_kernel(const float* __restrict__ row_recon, float recon_sign,
                                                               const float* __restrict__ row_kl, int B,
                                                               const double* __restrict__ mmd_part, int n_part,
@@ -54,8 +54,11 @@ __global__ __launch_bounds__(256) void finalize_losses_kernel(const float* __res
         losses[0] = (float)recon; losses[1] = (float)kl; losses[2] = (float)mm; losses[3] = (float)tot;
         if (accum) {
             // the reference logs float32 `.item()` values per iteration and averages them per epoch
-            accum[0] += (double)(float)recon; accum[1] += (double)(float)kl; accum[2] += (double)(float)mm;
-            accum[3] += (double)(float)tot; accum[4] += 1.0;
+            // hyper[6] = weight of this minibatch's means in the epoch log (1; n_local / n_global on a data-parallel
+            // rank, so that the all-reduced sums give the means over the GLOBAL minibatches also for ragged shards)
+            const double w = (double)hyper[6];
+            accum[0] += w * (double)(float)recon; accum[1] += w * (double)(float)kl; accum[2] += w * (double)(float)mm;
+            accum[3] += w * (double)(float)tot; accum[4] += w;
         }
     }
 }

@@ -113,7 +113,7 @@ extern "C" int sca_csr_gather_rows(const int64_t* indptr, const int32_t* indices
     if (B <= 0) return 0;
     if (G <= 0 || ldx < G) return -1;
     hipStream_t st = (hipStream_t)stream;
-    if (G <= 16384) {
+    if ((size_t)G * sizeof(float) + 64 <= 65536) {      // the LDS row + the static reduction scratch fit 64 KB
         // threads per cell (tuning knob, SCA_GATHER_T = 64 | 128 | 256): fewer threads = more cells in flight per CU
         static const int tsel = [] { const char* v = getenv("SCA_GATHER_T"); return v ? atoi(v) : 0; }();
         const int T = tsel ? tsel : (G <= 1024 ? 64 : G <= 4096 ? 128 : 256);

@@ -33,6 +33,19 @@ def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def broadcast_(t: torch.Tensor, src: int = 0) -> torch.Tensor:
+    """In-place broadcast from rank `src` (initial parameter / buffer synchronisation of the replicas)."""
+    if not is_dist():
+        return t
+    if _host_staged(t):
+        h = t.detach().cpu()
+        dist.broadcast(h, src)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src)
+    return t
+
+
 def all_gather_rows_(out: torch.Tensor, local: torch.Tensor) -> torch.Tensor:
     """out[world * n, ...] <- the ranks' equally sized `local[n, ...]` blocks in rank order."""
     if _host_staged(local):

@@ -75,6 +75,8 @@ class CVAEEngine:
 
     def __init__(self, spec: dict, named_params: "OrderedDict[str, torch.Tensor]", device):
         self._rec = None
+        self._ws_gen = 0
+        self._plans = {}
         self._mid_max_split = None      # optional split-K cap of the two GEMMs whose slabs the fused kernels sum
         self.lib = _RecordingLib(_lib.load(), self)
         self.device = torch.device(device)
@@ -242,6 +244,7 @@ class CVAEEngine:
         # pinned staging ring: an async H2D copy reads host memory when it executes, so each in-flight
         # update needs its own slot (an event per slot guards reuse)
         self._hyper_host = torch.zeros(8, dtype=torch.float32)
+        self._hyper_host[6] = 1.0       # epoch-log weight of a minibatch (set_hyper(log_weight=...) under DP)
         self._hyper_ring = torch.zeros(64, 8, dtype=torch.float32).pin_memory()
         self._hyper_ev = [None] * 64
         self._hyper_i = 0
@@ -268,8 +271,10 @@ class CVAEEngine:
                               and max(self.H) <= wmax and 3 * self.Zt <= wmax and bool(s.get("fused_mid", True)))
 
     # ------------------------------------------------------------------------------------------ configuration
-    def set_hyper(self, alpha_kl=None, lr=None, eps=None, clip=None, t=None):
+    def set_hyper(self, alpha_kl=None, lr=None, eps=None, clip=None, t=None, log_weight=None):
         h = self._hyper_host
+        if log_weight is not None:
+            h[6] = float(log_weight)
         if alpha_kl is not None:
             h[0] = float(alpha_kl)
         if lr is not None:
@@ -302,9 +307,19 @@ class CVAEEngine:
             self.trainable[k] = k in names
 
     # ------------------------------------------------------------------------------------------ workspaces
+    def _invalidate(self):
+        """Drop everything that holds raw workspace addresses (recorded launch plans, HIP graphs, cached kernel
+        argument blocks): called whenever a workspace buffer is (re)allocated."""
+        self._plans = {}
+        self._mid_cache = {}
+        self._gg_cache = {}
+        self._tail_cache = {}
+        self._ws_gen = getattr(self, "_ws_gen", 0) + 1
+
     def _ensure(self, B):
         if B <= self.Bcap:
             return
+        self._invalidate()
         dev, f32 = self.device, torch.float32
         G, C, Z, H = self.G, max(self.C, 1), self.Zt, self.H
         L = self.lib
@@ -366,21 +381,31 @@ class CVAEEngine:
         ws["dh0"] = torch.empty(B, H[0], dtype=f32, device=dev)
         # split-K slab workspace: the largest S*M*N over every GEMM of the step
         need = 0
+        Bsym = -1        # placeholder for "the batch size" in the shape list below
         shapes = []
         for ly in self.enc + self.dec:
-            shapes += [(B, ly.n_out, ly.n_in), (ly.n_out, ly.n_in, B), (B, ly.n_in, ly.n_out)]
-        shapes += [(B, 2 * Z, H[-1]), (2 * Z, H[-1], B), (B, H[-1], 2 * Z)]
+            shapes += [(Bsym, ly.n_out, ly.n_in), (ly.n_out, ly.n_in, Bsym), (Bsym, ly.n_in, ly.n_out)]
+        shapes += [(Bsym, 2 * Z, H[-1]), (2 * Z, H[-1], Bsym), (Bsym, H[-1], 2 * Z)]
         if self.cond_embed:
             for ly in self.enc + self.dec:
                 if ly.wc:
-                    shapes += [(B, self.E, ly.n_out), (ly.n_out, self.E, B)]
+                    shapes += [(Bsym, self.E, ly.n_out), (ly.n_out, self.E, Bsym)]
         if xp:
-            shapes += [(G, Z, B), (B, Z, G)]
+            shapes += [(G, Z, Bsym), (Bsym, Z, G)]
         else:
             Hl = self.dec[-1].n_out
-            shapes += [(G, Hl, B), (B, Hl, G)]
-        for (M, N, K) in shapes:
-            need = max(need, L.sca_gemm_splitk_heuristic(M, N, K) * M * N)
+            shapes += [(G, Hl, Bsym), (Bsym, Hl, G)]
+        # The split count is not monotone in the batch size (fewer 64-row tiles -> the planner doubles S again), so a
+        # ragged last minibatch / validation batch B' < B can need MORE slab floats than B itself: size for the worst
+        # case over every B' <= B (the plan only changes at multiples of 16 rows: k-tiles of 16, row tiles of 64).
+        cache = {}
+        for b in list(range(16, B, 16)) + [B]:
+            for (M, N, K) in shapes:
+                key = (b if M == Bsym else M, N, b if K == Bsym else K)
+                v = cache.get(key)
+                if v is None:
+                    v = cache[key] = L.sca_gemm_splitk_heuristic(*key) * key[0] * key[1]
+                need = max(need, v)
         ws["slab"] = torch.empty(need, dtype=f32, device=dev)
         ws["slab_aux"] = torch.empty(need, dtype=f32, device=dev)
         for ly in self.enc + self.dec:
@@ -478,6 +503,9 @@ class CVAEEngine:
                 rec.append(args)
             _lib.check(L.sca_gemm_f32(*args, st), "gemm")
             return out, 1, 0
+        if S * M * N > self.ws[slab_key].numel():
+            raise RuntimeError("split-K slabs of a %dx%dx%d GEMM (S=%d) exceed the workspace (%d floats)"
+                               % (M, N, K, S, self.ws[slab_key].numel()))
         slab = self.ws[slab_key].data_ptr()
         args = (am, bm, A, lda, Bm, ldb, slab, N, M, N, K, S, M * N, None)
         if rec is not None:
@@ -517,6 +545,8 @@ class CVAEEngine:
         key = "gslab:%d" % dst.data_ptr()
         slab = self.ws.get(key)
         if slab is None or slab.numel() < S * M * N:
+            if slab is not None:
+                self._invalidate()      # recorded plans hold the old address
             slab = self.ws[key] = torch.empty(S * M * N, dtype=torch.float32, device=self.device)
         args = (am, bm, A, lda, Bm, ldb, slab.data_ptr(), N, M, N, K, S, M * N, None)
         self._tail_jobs.append((0, S, M * N, slab.data_ptr(), dst.data_ptr(), M * N, 0, 0, 0, 0, 0))
@@ -930,7 +960,7 @@ class CVAEEngine:
     def _mid_args(self, B, cond_p, p_drop, eps, masks, dh=None, S=0, stride=0, dz2=None, pre0=None):
         """sca_mid_args for the current workspace (cached: every pointer is static for a given batch capacity)."""
         P, ws, ptr = self.p, self.ws, _lib.ptr
-        key = (B, id(ws), cond_p, p_drop, ptr(eps), tuple(sorted((k, v.data_ptr()) for k, v in masks.items())), dh, S,
+        key = (B, self._ws_gen, self.seed, cond_p, p_drop, ptr(eps), tuple(sorted((k, v.data_ptr()) for k, v in masks.items())), dh, S,
                stride, dz2, pre0)
         cache = self.__dict__.setdefault("_mid_cache", {})
         hit = cache.get(key)
@@ -1102,6 +1132,8 @@ class CVAEEngine:
         Ku = 0 if Pu is None else Pu.shape[0]
         need = L.sca_proto_workspace_bytes(B, K, Ku)
         if "proto_work" not in ws or ws["proto_work"].numel() < need:
+            if "proto_work" in ws:
+                self._invalidate()
             ws["proto_work"] = torch.empty(need, dtype=torch.uint8, device=self.device)
         ct, lab = proto.get("celltypes"), proto.get("labeled")
         eta, uw = float(proto.get("eta", 1.0)), float(proto.get("unlabeled_weight", 0.0))
@@ -1200,6 +1232,7 @@ class CVAEEngine:
 
     def _scratch_bh(self, B, Hd):
         if not hasattr(self, "_sbh") or self._sbh.numel() < B * Hd:
+            self._invalidate()
             self._sbh = torch.empty(B * Hd, dtype=torch.float32, device=self.device)
         return self._sbh[:B * Hd].view(B, Hd)
 
@@ -1245,7 +1278,7 @@ class CVAEEngine:
         cells per global minibatch).  Without it each rank takes the MMD of its own slice (a per-rank estimator).
         `gather(out, local)` replaces torch.distributed.all_gather_into_tensor (tests)."""
         self._dp = dict(rank=int(rank), world=int(world), exact=bool(exact_mmd) and world > 1, gather=gather)
-        self._plans = {}
+        self._invalidate()
 
     def _dp_exact(self):
         return self._dp is not None and self._dp["exact"] and self.use_mmd and self.C > 0
@@ -1339,6 +1372,7 @@ class CVAEEngine:
         else:
             n = self.lib.sca_mmd_num_partials(B, Dm)
         if self.ws["mmd_part"].numel() < n:
+            self._invalidate()
             self.ws["mmd_part"] = torch.zeros(n, dtype=torch.float64, device=self.device)
         return n
 
@@ -1376,11 +1410,15 @@ class CVAEEngine:
                 sdist.allreduce_mean_(self.flat_g, world, weight=grad_weight)
             self.adam_step(weight_decay, wd_overrides)
             return self.losses
-        key = (B, use_graph is True, float(weight_decay), tuple(sorted((wd_overrides or {}).items())), world > 1,
-               tuple(sorted(k for k, v in self.trainable.items() if v)), self.use_mmd, self.mmd_on, self.boundary,
-               self.beta, torch.cuda.current_stream(self.device).cuda_stream,
-               self._dp_n_global if dp_exact else None)
-        plans = self.__dict__.setdefault("_plans", {})
+        def plan_key():
+            return (B, use_graph is True, float(weight_decay), tuple(sorted((wd_overrides or {}).items())), world > 1,
+                    tuple(sorted(k for k, v in self.trainable.items() if v)), self.use_mmd, self.mmd_on,
+                    self.boundary, self.beta, torch.cuda.current_stream(self.device).cuda_stream,
+                    self._dp_n_global if dp_exact else None, self.hsic_beta, self.dr_rate, self.seed, self.freeze,
+                    self._ws_gen)
+        self._ensure(B)
+        key = plan_key()
+        plans = self._plans
         g = plans.get(key)
         fast = (g is not None and row_ids.dtype == torch.int64 and cond.dtype == torch.int32 and row_ids.is_cuda
                 and cond.is_cuda and row_ids.is_contiguous() and cond.is_contiguous()
@@ -1390,8 +1428,10 @@ class CVAEEngine:
         else:
             self.begin_step(alpha_kl, lr, eps, clip)
             if g is None:
-                g = plans[key] = (self._capture if use_graph is True else self._record)(B, weight_decay,
-                                                                                        wd_overrides, world > 1)
+                g = (self._capture if use_graph is True else self._record)(B, weight_decay, wd_overrides, world > 1)
+                # buffers allocated lazily during the warm-up pass bump the workspace generation (and drop the old
+                # plans): file the new plan under the generation it was recorded against
+                self._plans[plan_key()] = g
             g["rows"].copy_(row_ids, non_blocking=True)
             g["cond"].copy_(cond, non_blocking=True)
         if use_graph is True:

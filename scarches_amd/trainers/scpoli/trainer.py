@@ -109,6 +109,10 @@ class scPoliTrainer(Trainer):
         self.prototype_optim = None
 
         self.labeled_indices = range(len(adata)) if labeled_indices is None else labeled_indices
+        if self.world > 1:
+            # the reference's split shuffles with the unseeded global numpy RNG (trainers/scpoli/_utils.py:140,160);
+            # data-parallel ranks must build the SAME split, so they seed it alike
+            np.random.seed(self.seed)
         self.update_labeled_indices(self.labeled_indices)
         self.prototype_training = prototype_training
         self.unlabeled_prototype_training = unlabeled_prototype_training
@@ -163,6 +167,9 @@ class scPoliTrainer(Trainer):
         self.model.train()
         self.n_epochs = n_epochs
         self.engine = self.model.engine(self.device)
+        self._fresh_optimizer()
+        if self.world > 1:
+            self._sync_replicas()
         # two parameter groups: embeddings without weight decay, everything else with it
         self._wd_over = {k: 0.0 for k in self.engine.names if "embedding" in k}
         self.optimizer = _ParamGroups(lr, eps, self.weight_decay)
@@ -211,6 +218,7 @@ class scPoliTrainer(Trainer):
 
     def on_iteration(self, batch_data):
         eng = self.engine
+        self._set_log_weight(batch_data["rows"].numel(), batch_data["n_global"])
         eng.begin_step(alpha_kl=self.calc_alpha_coeff(), lr=self.optimizer.param_groups[0]["lr"], eps=self._eps,
                        clip=self.clip_value)
         if batch_data["rows"].numel() > 0:
@@ -407,10 +415,12 @@ class scPoliTrainer(Trainer):
         for lo in range(0, n, self._val_batch):
             b = perm[lo:lo + self._val_batch]
             if self.world > 1:
+                n_global = b.numel()
                 s, e = sdist.shard_range(b.numel(), self.rank, self.world)
                 b = b[s:e]
                 if b.numel() == 0:
                     continue
+                self._set_log_weight(b.numel(), n_global)
             eng.step_ctr += 1
             self.loss(self._batch(va, b), train=False)
         self._read_logs("val_")

@@ -99,6 +99,10 @@ class Trainer:
         self.val_iters_per_epoch = None
         self.logs = defaultdict(list)
 
+        if self.world > 1:
+            # without a condition key the split shuffles with the unseeded global numpy RNG (trainers/trvae/_utils.py:
+            # 128-143); data-parallel ranks must build the SAME split, so they seed it alike
+            np.random.seed(self.seed)
         self.train_data, self.valid_data = make_dataset(
             self.adata, train_frac=self.train_frac, condition_key=self.condition_key,
             cell_type_keys=self.cell_type_keys, condition_encoder=self.model.condition_encoder,
@@ -158,8 +162,10 @@ class Trainer:
         self.model.train()
         self.n_epochs = n_epochs
         self.engine = self.model.engine(self.device)          # also syncs requires_grad -> trainable set
+        self._fresh_optimizer()
         if self.world > 1:
             self.engine.set_dp(self.rank, self.world, exact_mmd=self.dp_exact_mmd)
+            self._sync_replicas()
         self.optimizer = _ParamGroups(lr, eps, self.weight_decay)
         self._eps = eps
         tr = self._train_dev
@@ -182,6 +188,24 @@ class Trainer:
         torch.cuda.synchronize(self.device)
         self.training_time += (time.time() - begin)
 
+    def _fresh_optimizer(self):
+        """The reference builds a new torch.optim.Adam in every train() (trainer.py:221-223): moments and the
+        bias-correction step restart from zero; the engine's Philox seed follows this trainer's seed."""
+        eng = self.engine
+        eng.flat_m.zero_()
+        eng.flat_v.zero_()
+        eng.adam_t = 0
+        eng.seed = int(self.model.seed)
+
+    def _sync_replicas(self):
+        """Data-parallel start state: rank 0's parameters and BatchNorm buffers are broadcast so that every replica
+        starts from the same model whatever the ranks' RNG state at construction time (what DDP does in its
+        constructor); the replicas then stay identical because they apply identical all-reduced gradients."""
+        eng = self.engine
+        sdist.broadcast_(eng.flat_p, 0)
+        for k in sorted(eng.buffers):
+            sdist.broadcast_(eng.buffers[k], 0)
+
     def before_loop(self):
         pass
 
@@ -203,6 +227,7 @@ class Trainer:
         rows, cond, n_global = batch_data
         kw = dict(alpha_kl=self.calc_alpha_coeff(), lr=self.optimizer.param_groups[0]["lr"], eps=self._eps,
                   clip=self.clip_value)
+        self._set_log_weight(rows.numel(), n_global)
         if rows.numel() == 0:           # a rank whose slice of a tiny last minibatch is empty contributes zeros
             eng.begin_step(**kw)
             eng.dp_idle_step(n_global)
@@ -214,6 +239,16 @@ class Trainer:
                                            world=self.world, use_graph=self.launch_mode,
                                            grad_weight=rows.numel() / n_global if self.world > 1 else None,
                                            n_global=n_global if self.world > 1 else None, **kw)
+
+    def _set_log_weight(self, n_local, n_global):
+        """Data-parallel epoch logs: a rank's minibatch means enter the accumulators with weight n_local / n_global,
+        so the all-reduced sums are the means over the GLOBAL minibatches also when the shards are ragged."""
+        if self.world <= 1:
+            return
+        w = n_local / float(max(n_global, 1))
+        if w != getattr(self, "_log_w", None):
+            self.engine.set_hyper(log_weight=w)
+            self._log_w = w
 
     def _read_logs(self, prefix):
         acc = self.engine.accum.clone()
@@ -255,6 +290,7 @@ class Trainer:
                 if b.numel() == 0:
                     eng.dp_idle_step(n_global)
                     continue
+            self._set_log_weight(b.numel(), n_global)
             c = va["cond"][b]
             order = torch.argsort(c, stable=True)
             eng.step_ctr += 1

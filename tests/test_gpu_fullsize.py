@@ -260,3 +260,67 @@ def test_smaller_minibatch_after_the_full_one(data, n_small):
     torch.cuda.synchronize()
     assert np.all(np.abs(a.losses.cpu().numpy()[:3] - l_big[:3]) <= 1e-6 * np.abs(l_big[:3]))
     assert_grads_close(grads(a), g_big, rtol=1e-5)
+
+
+def test_split_k_slabs_of_a_smaller_minibatch_fit(data):
+    """The split-K count is not monotone in the batch size: with G = 2000 and a 256-wide first layer a 960-row
+    minibatch takes S = 32 slabs where the 1024-row one takes 16, i.e. 1.9x the slab floats.  The slab workspaces are
+    sized for the worst case over every B' <= B; a canary behind each stays intact, and the 960-row step equals that
+    of a fresh engine that only ever saw 960 rows."""
+    L = __import__("scarches_amd._lib", fromlist=["load"]).load()
+    Hh = [256, 64]
+    a, b = make_engine(data, H=Hh, dr_rate=0.0, fused_mid=False), make_engine(data, H=Hh, dr_rate=0.0, fused_mid=False)
+    n_big, n_small = 1024, 960
+    assert (L.sca_gemm_splitk_heuristic(n_small, 256, G) * n_small * 256
+            > L.sca_gemm_splitk_heuristic(n_big, 256, G) * n_big * 256)        # the shape that used to overflow
+    a._ensure(n_big)
+    need = a.ws["slab"].numel()
+    assert need >= L.sca_gemm_splitk_heuristic(n_small, 256, G) * n_small * 256
+    # canaries: re-home both slab workspaces inside larger allocations whose tails must stay untouched
+    for key in ("slab", "slab_aux"):
+        big = torch.full((need + 4096,), 123.0, device="cuda")
+        a.ws[key] = big[:need]
+        a.ws[key + "_canary"] = big
+    a._invalidate()
+    for n in (n_big, n_small):
+        rows, cond = data["rows"][:n].contiguous(), data["cond"][:n].contiguous()
+        eps = torch.randn(n, Z, device="cuda")
+        for e in ((a, b) if n == n_small else (a,)):
+            e.begin_step(alpha_kl=0.5, lr=1e-3)
+            e.forward_backward(rows, cond, n, eps=eps)
+        torch.cuda.synchronize()
+        for key in ("slab", "slab_aux"):
+            assert bool((a.ws[key + "_canary"][need:] == 123.0).all()), (key, n)
+    la, lb = a.losses.cpu().numpy(), b.losses.cpu().numpy()
+    assert np.all(np.abs(la[:3] - lb[:3]) <= 1e-5 * np.abs(lb[:3]) + 1e-7), (la, lb)
+    assert_grads_close(grads(a), grads(b))
+    with pytest.raises(RuntimeError):       # a GEMM whose slabs do not fit is refused, never launched
+        a.ws["slab"] = a.ws["slab"][:1024]
+        a._gemm(0, 0, a.ws["x"].data_ptr(), G, a.p["encoder.FC.L0.expr_L.weight"].data_ptr(), G, n_small, 256, G, 0)
+
+
+@pytest.mark.parametrize("mode", ["plan", True])
+def test_recorded_plans_survive_a_workspace_regrowth(data, mode):
+    """train -> encode more cells than the training batch (the workspaces are reallocated) -> train again: recorded
+    launch plans / HIP graphs hold raw workspace addresses and must be dropped with the old buffers.  The trajectory
+    equals that of an engine that runs the same steps eagerly."""
+    n, n_enc = 512, 3000
+    rows, cond = data["rows"][:n].contiguous(), data["cond"][:n].contiguous()
+    engs = [make_engine(data), make_engine(data)]
+    for eng, m in zip(engs, (mode, False)):
+        for _ in range(3):
+            eng.train_step(rows, cond, n, 0.5, 1e-3, use_graph=m)
+        gen0 = eng._ws_gen
+        z, mu, _ = eng.encode(data["rows"][:n_enc].contiguous(), data["cond"][:n_enc].contiguous(), n_enc)
+        assert eng._ws_gen > gen0 and not eng._plans
+        junk = [torch.full((n_enc, G), float("nan"), device="cuda") for _ in range(4)]   # reuse freed blocks
+        for _ in range(3):
+            eng.train_step(rows, cond, n, 0.5, 1e-3, use_graph=m)
+        torch.cuda.synchronize()
+        del junk
+    a, b = engs
+    assert torch.isfinite(a.flat_p).all()
+    la, lb = a.losses.cpu().numpy(), b.losses.cpu().numpy()
+    assert np.all(np.abs(la[:3] - lb[:3]) <= 2e-5 * np.abs(lb[:3]) + 1e-7), (la, lb)
+    d = float((a.flat_p - b.flat_p).abs().max())
+    assert d <= 1e-5 * float(b.flat_p.abs().max()), d
