@@ -231,6 +231,30 @@ class CVAEEngine:
                 k = f"{ly.bn}.num_batches_tracked"
                 t = given.get(k)
                 self.buffers[k] = (torch.zeros((), dtype=torch.long) if t is None else t.detach()).to(dev).clone()
+        # operand shapes the kernels and their grids assume, checked on the host before anything is launched
+        def _expect(k, shape):
+            if k is not None and self.shapes.get(k) != tuple(shape):
+                raise ValueError("parameter %r has shape %r, the architecture (G=%d, H=%r, Z=%d, C=%d) needs %r"
+                                 % (k, self.shapes.get(k), G, H, self.Zt, self.C, tuple(shape)))
+        for ly in self.enc + self.dec:
+            _expect(ly.w, (ly.n_out, ly.n_in))
+            _expect(ly.b, (ly.n_out,))
+            _expect(ly.wc, (ly.n_out, self.E if self.cond_embed else self.C))
+            if ly.bn:
+                _expect(ly.bn + ".weight", (ly.n_out,))
+                _expect(ly.bn + ".bias", (ly.n_out,))
+        if self.out_w:
+            _expect(self.out_w, (G, Hd[-1]))
+            _expect(self.out_b, (G,))
+            if self.recon == "zinb":
+                _expect("decoder.dropout_decoder.weight", (G, Hd[-1]))
+                _expect("decoder.dropout_decoder.bias", (G,))
+        if self.recon != "mse" and self.C > 0:
+            _expect("theta", (G, self.C))
+        for k in fused_w:
+            _expect(k, (self.Zx if "expand" in k else Z, H[-1]))
+        for k, n, e in self.emb:
+            _expect(k, (n, e))
         Zt = self.Zt
         ow, ob = self.offsets[fused_w[0]], self.offsets[fused_b[0]]
         self.heads_w = self.flat_p[ow:ow + 2 * Zt * H[-1]].view(2 * Zt, H[-1])
@@ -310,6 +334,9 @@ class CVAEEngine:
     def _invalidate(self):
         """Drop everything that holds raw workspace addresses (recorded launch plans, HIP graphs, cached kernel
         argument blocks): called whenever a workspace buffer is (re)allocated."""
+        if getattr(self, "_plans", None):
+            # a HIP graph must not be destroyed (nor its buffers freed) while its last replay is still running
+            torch.cuda.synchronize(self.device)
         self._plans = {}
         self._mid_cache = {}
         self._gg_cache = {}

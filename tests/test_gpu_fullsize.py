@@ -36,7 +36,7 @@ def make_engine(data, **over):
     spec = dict(G=G, C=C, H=H, Z=Z, recon="nb", use_bn=False, use_ln=True, use_mmd=True, mmd_on="z", boundary=None,
                 beta=1.0, dr_rate=0.05, seed=2020)
     spec.update(over)
-    eng = CVAEEngine(spec, build_trvae_params(G, C, H, Z), "cuda:0")
+    eng = CVAEEngine(spec, build_trvae_params(spec["G"], spec["C"], spec["H"], spec["Z"]), "cuda:0")
     eng.bind_csr(*data["csr"])
     return eng
 
