@@ -287,6 +287,19 @@ int sca_knn_topk(const float* ref, int Nr, const float* qry, int Nq, int D, int 
 int sca_knn_vote(const float* dist, const int32_t* idx, int Nq, int k, const int32_t* labels, int32_t* pred,
                  double* prob, void* stream);
 
+/* sca_knn_topk_static: sca_knn_topk WITHOUT a caller workspace and without any allocation.  It has no counterpart in
+ * the reference; it is for callers that cannot allocate device memory - code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc.  Same kernels, same results (bit for bit) as sca_knn_topk; the partial
+ * top-k lists live in a 16 MiB file-scope device array of the library (one copy per GPU the library runs on, held
+ * until the process ends), whose per-device address is looked up once with hipGetSymbolAddress.  Limit:
+ * sca_knn_num_chunks(Nr, Nq) * Nq * k <= sca_knn_static_max_entries() (= 2^21; e.g. 32768 queries at k = 50 against
+ * any reference size); larger problems return -3 and belong to sca_knn_topk.  The array keeps the previous call's
+ * contents; nothing needs clearing (every partial entry that is read is written first).  Calls that overlap on one
+ * GPU (different streams) share the array and race: issue them on one stream.  Calls no hipMalloc / hipFree. */
+long long sca_knn_static_max_entries(void);
+int sca_knn_topk_static(const float* ref, int Nr, const float* qry, int Nq, int D, int k, float* dist, int32_t* idx,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -99,6 +99,8 @@ SIGNATURES = {
     "sca_knn_num_chunks": [I, I],
     "sca_knn_topk": [P, I, P, I, I, I, P, P, P, P, P],
     "sca_knn_vote": [P, P, I, I, P, P, P, P],
+    "sca_knn_static_max_entries": [],
+    "sca_knn_topk_static": [P, I, P, I, I, I, P, P, P],
     "sca_grad_tail_max_jobs": [],
     "sca_grad_tail": [P, I, P],
     "sca_bn_fwd": [P, I, I, P, P, P, P, I, I, F, F, P, U64, U32, P, P, P, P, P],
@@ -110,7 +112,7 @@ SIGNATURES = {
     "sca_class_moments": [P, I, I, I, P, I, P, I, P, P, P, P],
     "sca_class_moments_finish": [P, P, P, I, I, P, P, P, P, P, P],
 }
-RESTYPES = {"sca_hsic_workspace_floats": LL, "sca_proto_workspace_bytes": LL}
+RESTYPES = {"sca_hsic_workspace_floats": LL, "sca_proto_workspace_bytes": LL, "sca_knn_static_max_entries": LL}
 
 _lib = None
 

@@ -10,6 +10,7 @@
 // second kernel merges the partial lists and sorts them ascending.
 // Algorithmic work per query: 3 D Nr flop; the reference is read from HBM/L2 once per 32 queries.
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -229,12 +230,9 @@ extern "C" int sca_knn_num_chunks(int Nr, int Nq) {
     return (int)chunks;
 }
 
-extern "C" int sca_knn_topk(const float* ref, int Nr, const float* qry, int Nq, int D, int k, float* pd2,
-                            int32_t* pidx, float* dist, int32_t* idx, void* stream) {
-    if (Nq <= 0) return 0;
-    if (Nr <= 0 || D <= 0 || k <= 0) return -1;
-    if (k > KNN_KMAX || k > Nr || D > 64) return -2;
-    hipStream_t st = (hipStream_t)stream;
+// Shared launcher of the two top-k entry points: scan over reference chunks into the partial lists, then merge.
+static int knn_topk_launch(const float* ref, int Nr, const float* qry, int Nq, int D, int k, float* pd2,
+                           int32_t* pidx, float* dist, int32_t* idx, hipStream_t st) {
     const int chunks = sca_knn_num_chunks(Nr, Nq);
     int chunk = (Nr + chunks - 1) / chunks;
     chunk = ((chunk + KNN_RT - 1) / KNN_RT) * KNN_RT;
@@ -253,6 +251,65 @@ extern "C" int sca_knn_topk(const float* ref, int Nr, const float* qry, int Nq, 
                        dist, idx);
     SCA_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int sca_knn_topk(const float* ref, int Nr, const float* qry, int Nq, int D, int k, float* pd2,
+                            int32_t* pidx, float* dist, int32_t* idx, void* stream) {
+    if (Nq <= 0) return 0;
+    if (Nr <= 0 || D <= 0 || k <= 0) return -1;
+    if (k > KNN_KMAX || k > Nr || D > 64) return -2;
+    return knn_topk_launch(ref, Nr, qry, Nq, D, k, pd2, pidx, dist, idx, (hipStream_t)stream);
+}
+
+// ---- sca_knn_topk without a caller workspace and without any allocation ------------------------------------------
+// For callers that cannot allocate (code under HIP graph capture, serving loops, harnesses that forbid hipMalloc): the
+// partial top-k lists live in a file-scope device array of the library, SCA_KNN_STATIC_ENTRIES (distance, index) pairs
+// = 16 MiB per GPU the library runs on, held until the process ends.  The array's name is only a host-side handle:
+// its device address is looked up once per device with hipGetSymbolAddress (each GPU has its own copy at its own
+// address) and only that pointer is handed to the kernels.  Nothing has to be cleared between calls: the scan kernel
+// writes every partial entry the merge kernel reads.  Calls that overlap on one GPU (different streams) share the
+// array and race; issue them on one stream.
+constexpr long long SCA_KNN_STATIC_ENTRIES = 2ll << 20;
+static __device__ __align__(256) unsigned char scratch[SCA_KNN_STATIC_ENTRIES * 8];
+
+namespace {
+constexpr int KNN_MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+unsigned char* g_scratch_ptr[KNN_MAX_DEVICES] = {};      // per device: address of `scratch` on that GPU
+
+int knn_scratch_for_current_device(unsigned char** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= KNN_MAX_DEVICES) return -4;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void* p = nullptr;
+        e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));     // with device `dev` current: this GPU's copy
+        if (e != hipSuccess) return (int)e;
+        if (p == nullptr) return -4;
+        g_scratch_ptr[dev] = static_cast<unsigned char*>(p);
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+}  // namespace
+
+extern "C" long long sca_knn_static_max_entries(void) { return SCA_KNN_STATIC_ENTRIES; }
+
+extern "C" int sca_knn_topk_static(const float* ref, int Nr, const float* qry, int Nq, int D, int k, float* dist,
+                                   int32_t* idx, void* stream) {
+    if (Nq <= 0) return 0;
+    if (Nr <= 0 || D <= 0 || k <= 0) return -1;
+    if (k > KNN_KMAX || k > Nr || D > 64) return -2;
+    const long long entries = (long long)sca_knn_num_chunks(Nr, Nq) * Nq * k;
+    if (entries > SCA_KNN_STATIC_ENTRIES) return -3;          // beyond the static workspace: use sca_knn_topk
+    unsigned char* base = nullptr;
+    const int rc = knn_scratch_for_current_device(&base);
+    if (rc) return rc;
+    float* pd2 = reinterpret_cast<float*>(base);
+    int32_t* pidx = reinterpret_cast<int32_t*>(base + SCA_KNN_STATIC_ENTRIES * 4);
+    return knn_topk_launch(ref, Nr, qry, Nq, D, k, pd2, pidx, dist, idx, (hipStream_t)stream);
 }
 
 extern "C" int sca_knn_vote(const float* dist, const int32_t* idx, int Nq, int k, const int32_t* labels, int32_t* pred,
