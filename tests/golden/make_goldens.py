@@ -344,7 +344,7 @@ def main():
     rng = np.random.default_rng(20240521)
     run_trvae_case("trvae_nb_ln_small", rng, G=64, C=3, H=[32, 16], Z=5, B=16, recon="nb", use_bn=False,
                    use_ln=True, use_mmd=True, mmd_on="z", boundary=None, beta=1.0, adam_steps=3, seed=1)
-    run_trvae_case("trvae_nb_ln_cfg2", rng, G=200, C=20, H=[128, 128], Z=10, B=128, recon="nb", use_bn=False,
+    run_trvae_case("trvae_nb_ln_g200_c20", rng, G=200, C=20, H=[128, 128], Z=10, B=128, recon="nb", use_bn=False,
                    use_ln=True, use_mmd=True, mmd_on="z", boundary=None, beta=1.0, seed=2)
     run_trvae_case("trvae_zinb_bn", rng, G=48, C=4, H=[24], Z=4, B=32, recon="zinb", use_bn=True,
                    use_ln=False, use_mmd=False, mmd_on="z", boundary=None, beta=1.0, seed=3)

@@ -6,7 +6,7 @@ import torch
 
 from oracle import cvae_oracle as O
 from oracle import expimap_oracle as E
-from tests._util import GOLDEN, dense_from_case, grads_close, load_case, rel_err
+from tests._util import GOLDEN, dense_from_case, golden_ref64, grads_close, load_case, rel_err
 
 torch.set_num_threads(1)
 TOL = 1e-5
@@ -36,7 +36,7 @@ def test_expimap_losses_and_grads(name):
     if cfg["use_hsic"]:
         # sqrt of a difference of O(1) means: fp32 cancellation noise of the reference itself
         assert abs(res["hsic"] - float(z["hsic"])) <= 1e-4 * abs(float(z["hsic"]))
-    bad = grads_close({k: v.numpy() for k, v in grads.items()}, Gr, rtol=2e-4 if cfg["use_hsic"] else 5e-5)
+    bad = grads_close({k: v.numpy() for k, v in grads.items()}, Gr, rtol=1e-5, ref64=golden_ref64(name)[1])
     assert not bad, bad
     # hard-masked entries carry exactly zero gradient
     if not cfg["soft_mask"]:
