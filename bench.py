@@ -270,8 +270,10 @@ def main():
         eng.forward_backward(ids[0], cs[0], B)
         calls = eng.record_gemms
         eng.record_gemms = None
-        single = [c for c in calls if c[0] != "group"] + [j for c in calls if c[0] == "group" for j in c[2]]
+        single = ([c for c in calls if c[0] not in ("group", "kk")]
+                  + [j for c in calls if c[0] == "group" for j in c[2]])
         flops = sum(2.0 * c[8] * c[9] * c[10] for c in single)
+        flops += sum(2.0 * c[1][6] * c[1][7] * c[1][8] for c in calls if c[0] == "kk")
         st = torch.cuda.current_stream(dev)
         for _ in range(3):
             eng.replay_gemms(calls)

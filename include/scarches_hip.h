@@ -55,6 +55,18 @@ typedef struct {
 int sca_gemm_group_max_jobs(void);
 int sca_gemm_group_f32(const sca_gemm_job* jobs, int n, void* stream);
 
+/* Register-direct kernel for two k-major operands, C (+ slabs) = A^T B with A(m,k) = A[k*lda+m], B(k,n) = B[k*ldb+n]
+ * (the amode == bmode == 1 case of sca_gemm_f32: the weight-gradient products dW = dY^T X that torch autograd issues
+ * per nn.Linear, scarches/models/trvae/modules.py:21-27,77,159,173-181).  MFMA fragments are loaded straight from
+ * global memory (no LDS staging, no barrier in the k loop); a launch writes `splitk` slabs, each already summed over
+ * 4 wave-level k ranges.  Requires sca_gemm_kk_supported(...) == 1 (lda % 4 == 0, M % 4 == 0, ldb % 2 == 0,
+ * N % 2 == 0, 16- / 8-byte aligned bases); returns -2 otherwise.  sca_gemm_kk_splitk_heuristic: the slab count the
+ * engine sizes its workspaces for. */
+int sca_gemm_kk_splitk_heuristic(int M, int N, int K);
+int sca_gemm_kk_supported(const float* A, int lda, const float* B, int ldb, int M, int N);
+int sca_gemm_kk_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                    int splitk, long long slab_stride, void* stream);
+
 /* Same with an explicit block tile (64*tile_wm) x (64*tile_wn), tile_w* in {1,2}; 0 = automatic (tuning hook). */
 int sca_gemm_f32_cfg(int amode, int bmode, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M,
                      int N, int K, int splitk, long long slab_stride, const float* bias, int tile_wm, int tile_wn,

@@ -65,6 +65,9 @@ SIGNATURES = {
     "sca_gemm_f32": [I, I, P, I, P, I, P, I, I, I, I, I, LL, P, P],
     "sca_gemm_f32_cfg": [I, I, P, I, P, I, P, I, I, I, I, I, LL, P, I, I, P],
     "sca_splitk_reduce": [P, I, LL, P, LL, P],
+    "sca_gemm_kk_splitk_heuristic": [I, I, I],
+    "sca_gemm_kk_f32": [P, I, P, I, P, I, I, I, I, I, LL, P],
+    "sca_gemm_kk_supported": [P, I, P, I, I, I],
     "sca_gemm_group_max_jobs": [],
     "sca_gemm_group_f32": [P, I, P],
     "sca_layer_fwd": [P, I, LL, I, I, P, P, I, P, P, I, I, I, F, P, U64, U32, P, P, P, P, P],

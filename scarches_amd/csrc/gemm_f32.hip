@@ -314,6 +314,168 @@ __global__ __launch_bounds__(256, GEMM_OCC) void gemm_group_kernel(const GroupAr
     else gemm_body<1, 1, false, 1, 1>(g.job[j], local - zs * g.tiles[j], zs, lds);
 }
 
+// ---- register-direct GEMM for two k-major operands (the weight-gradient family dW = dY^T X) ------------------------
+//   C[m][n] = sum_k A[k*lda + m] * B[k*ldb + n]
+// Both operands are contracted over their ROWS, so a wave can load MFMA fragments straight from global memory: the A
+// fragment of v_mfma_f32_32x32x2_f32 is "lane l holds A(m_l, k = l/32)".  Which 32 output rows a fragment covers is
+// free, so lane l loads a float4 at m = m0 + 4*(l%32) .. +3 of row k (lanes 0-31) / k+1 (lanes 32-63): ONE 16-byte
+// load per lane yields the fragments of four interleaved row blocks (block c = rows m0 + 4 i + c) - two fully
+// coalesced 512-byte segments per wave instruction; a float2 of B likewise yields two column blocks.  No LDS staging
+// and no workgroup barrier in the k loop.  A wave owns a 128 x 64 output tile (8 MFMA tiles: 2 load instructions feed 8
+// MFMAs = 512 matrix-pipe cycles) and keeps the fragments of the next TWO 16-row k blocks in flight in two further
+// register sets (~3.4 us of matrix work: HBM latency) - one wave per SIMD, ~300 VGPRs.  The four waves of a workgroup
+// take four consecutive k ranges of the SAME output tile (intra-workgroup split-K) and combine through LDS in a fixed
+// order (deterministic), so a launch writes `splitk` slabs while contracting over 4 * splitk ranges.
+// Needs lda % 4 == 0, M % 4 == 0, ldb % 2 == 0, N % 2 == 0 and 16- / 8-byte aligned bases (kk_shape_ok).
+constexpr int KK_U = 8;                 // k pairs per register set (16 k rows)
+constexpr int KK_BM = 128, KK_BN = 64;
+struct KKArgs {
+    const float* A; const float* B; float* C;
+    int lda, ldb, ldc, M, N, K;
+    int k_chunk;                        // k rows per WAVE (multiple of 16)
+    int tiles_m, tiles_n, n_fast;
+    long long slab_stride;
+};
+
+__device__ __forceinline__ void kk_body(const KKArgs& a, int tile, int zs, float* __restrict__ lds) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+    const int tm = a.n_fast ? tile / a.tiles_n : tile % a.tiles_m;
+    const int tn = a.n_fast ? tile % a.tiles_n : tile / a.tiles_m;
+    const int m0 = tm * KK_BM, n0 = tn * KK_BN;
+    const int kbeg = min(a.K, (zs * 4 + w) * a.k_chunk), kend = min(a.K, kbeg + a.k_chunk);
+    // columns past the operand's end are clamped: they only feed outputs that are never stored
+    const float* pa = a.A + min(m0 + 4 * l31, a.M - 4);
+    const float* pb = a.B + min(n0 + 2 * l31, a.N - 2);
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float4 ra[3][KK_U];
+    float2 rb[3][KK_U];
+    auto load = [&](auto SS, int k0) {
+        constexpr int S = decltype(SS)::value;
+#pragma unroll
+        for (int u = 0; u < KK_U; ++u) {
+            const long long k = k0 + 2 * u + half;
+            ra[S][u] = *reinterpret_cast<const float4*>(pa + k * a.lda);
+            rb[S][u] = *reinterpret_cast<const float2*>(pb + k * a.ldb);
+        }
+    };
+    auto mma4 = [&](const float4& x, const float2& y) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, y.x, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, y.y, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, y.x, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, y.y, acc[1][1], 0, 0, 0);
+        acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, y.x, acc[2][0], 0, 0, 0);
+        acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, y.y, acc[2][1], 0, 0, 0);
+        acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, y.x, acc[3][0], 0, 0, 0);
+        acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, y.y, acc[3][1], 0, 0, 0);
+    };
+    auto mma = [&](auto SS) {
+        constexpr int S = decltype(SS)::value;
+#pragma unroll
+        for (int u = 0; u < KK_U; ++u) mma4(ra[S][u], rb[S][u]);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
+    constexpr int KB = 2 * KK_U;
+    const int nblk = (kend - kbeg) / KB;
+    // block b lives in register set b % 3; blocks b+1 and b+2 are in flight while block b feeds the MFMAs
+    if (nblk > 0) load(S0{}, kbeg);
+    if (nblk > 1) load(S1{}, kbeg + KB);
+    int b = 0;
+    for (; b + 3 <= nblk; b += 3) {
+        if (b + 2 < nblk) load(S2{}, kbeg + (b + 2) * KB);
+        mma(S0{});
+        if (b + 3 < nblk) load(S0{}, kbeg + (b + 3) * KB);
+        mma(S1{});
+        if (b + 4 < nblk) load(S1{}, kbeg + (b + 4) * KB);
+        mma(S2{});
+    }
+    if (b < nblk) {                  // one or two blocks left (their loads are already in flight: sets 0 and 1)
+        mma(S0{});
+        if (b + 1 < nblk) mma(S1{});
+    }
+    // k tail (< 16 rows): rows past kend contribute zeros
+    for (int k0 = kbeg + nblk * KB; k0 < kend; k0 += 2) {
+        const int k = k0 + half;
+        const bool ok = k < kend;
+        const long long kc = ok ? k : kend - 1;
+        float4 x = *reinterpret_cast<const float4*>(pa + kc * a.lda);
+        float2 y = *reinterpret_cast<const float2*>(pb + kc * a.ldb);
+        if (!ok) { x = make_float4(0.f, 0.f, 0.f, 0.f); y = make_float2(0.f, 0.f); }
+        mma4(x, y);
+    }
+    // combine the four waves' partial tiles: (w0 + w2) + (w1 + w3), always in this order.
+    // acc[c][j][r] is output (m0 + 4 * row(r) + c, n0 + 2 * l31 + j), row(r) = (r & 3) + 8 (r >> 2) + 4 half
+    float* buf = lds + (w & 1) * (KK_BM * KK_BN);
+    auto at = [&](int c, int j, int r) { return (4 * ((r & 3) + 8 * (r >> 2) + 4 * half) + c) * KK_BN + 2 * l31 + j; };
+    if (w < 2) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                *reinterpret_cast<float2*>(&buf[at(c, 0, r)]) = make_float2(acc[c][0][r], acc[c][1][r]);
+    }
+    __syncthreads();
+    if (w >= 2) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float2* p = reinterpret_cast<float2*>(&buf[at(c, 0, r)]);
+                const float2 v = *p;
+                *p = make_float2(v.x + acc[c][0][r], v.y + acc[c][1][r]);
+            }
+    }
+    __syncthreads();
+    float* C = a.C + (long long)zs * a.slab_stride;
+    const bool vec = (a.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0 && n0 + KK_BN <= a.N;
+#pragma unroll
+    for (int q = 0; q < KK_BM / 16; ++q) {
+        const int row = (threadIdx.x >> 4) + 16 * q, col = 4 * (threadIdx.x & 15);
+        const int m = m0 + row;
+        if (m >= a.M) continue;
+        const float4 x = *reinterpret_cast<const float4*>(&lds[row * KK_BN + col]);
+        const float4 y = *reinterpret_cast<const float4*>(&lds[KK_BM * KK_BN + row * KK_BN + col]);
+        const float4 s = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+        float* dst = C + (long long)m * a.ldc + n0 + col;
+        if (vec) {
+            *reinterpret_cast<float4*>(dst) = s;
+        } else {
+            if (n0 + col + 0 < a.N) dst[0] = s.x;
+            if (n0 + col + 1 < a.N) dst[1] = s.y;
+            if (n0 + col + 2 < a.N) dst[2] = s.z;
+            if (n0 + col + 3 < a.N) dst[3] = s.w;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void gemm_kk_kernel(const KKArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float kk_lds[];
+    kk_body(a, blockIdx.x, blockIdx.z, kk_lds);
+}
+
+constexpr int KK_GROUP_MAX = 8;
+struct KKGroupArgs {
+    KKArgs job[KK_GROUP_MAX];
+    int wg_begin[KK_GROUP_MAX + 1];
+    int tiles[KK_GROUP_MAX];
+    int n;
+};
+__global__ __launch_bounds__(256, 1) void gemm_kk_group_kernel(const KKGroupArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int j = 0;
+    while (j + 1 < g.n && (int)blockIdx.x >= g.wg_begin[j + 1]) ++j;
+    const int local = blockIdx.x - g.wg_begin[j];
+    const int zs = local / g.tiles[j];
+    kk_body(g.job[j], local - zs * g.tiles[j], zs, lds);
+}
+
 // Sum S slabs into dst: dst[i] = sum_s slabs[s*stride + i].  4 independent accumulation chains keep several
 // slab loads in flight per lane (the slabs are L2/Infinity-Cache resident right after the GEMM).
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slabs, int S, long long stride,
@@ -374,6 +536,57 @@ static GemmPlan plan_gemm(int M, int N, int K) {
 }
 
 extern "C" int sca_gemm_splitk_heuristic(int M, int N, int K) { return plan_gemm(M, N, K).S; }
+
+// Split plan of the register-direct k-major kernel (gemm_kk_kernel): `S` slabs, each summed over 4 wave-level k ranges.
+// One workgroup (4 waves = one per SIMD, ~300 VGPRs, 64 KB LDS) per CU: target 256 workgroups; a wave keeps at least
+// three 16-row register sets of work.
+static int plan_kk(int M, int N, int K) {
+    const long long tiles = (long long)((M + KK_BM - 1) / KK_BM) * ((N + KK_BN - 1) / KK_BN);
+    static const int wg_target = [] { const char* v = getenv("SCA_GEMM_KK_WG"); return v ? atoi(v) : 256; }();
+    long long S = (wg_target + tiles - 1) / tiles;
+    const long long smax = K / (4 * 48);
+    if (S > smax) S = smax;
+    if (S > 64) S = 64;
+    if (S < 1) S = 1;
+    return (int)S;
+}
+extern "C" int sca_gemm_kk_splitk_heuristic(int M, int N, int K) { return plan_kk(M, N, K); }
+static bool kk_shape_ok(const float* A, int lda, const float* B, int ldb, int M, int N) {
+    static const bool on = [] { const char* v = getenv("SCA_GEMM_KK"); return !v || atoi(v) != 0; }();
+    return on && (lda & 3) == 0 && (M & 3) == 0 && M >= 4 && (ldb & 1) == 0 && (N & 1) == 0 && N >= 2 &&
+           ((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 7) == 0;
+}
+extern "C" int sca_gemm_kk_supported(const float* A, int lda, const float* B, int ldb, int M, int N) {
+    return kk_shape_ok(A, lda, B, ldb, M, N) ? 1 : 0;
+}
+constexpr size_t KK_LDS_BYTES = 2 * KK_BM * KK_BN * sizeof(float);
+static void fill_kk(KKArgs& a, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                    int splitk, long long slab_stride) {
+    a.A = A; a.B = B; a.C = C; a.lda = lda; a.ldb = ldb; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+    const int per = (K + 4 * splitk - 1) / (4 * splitk);
+    a.k_chunk = ((per + 2 * KK_U - 1) / (2 * KK_U)) * (2 * KK_U);
+    a.tiles_m = (M + KK_BM - 1) / KK_BM;
+    a.tiles_n = (N + KK_BN - 1) / KK_BN;
+    a.n_fast = a.tiles_n > a.tiles_m;
+    a.slab_stride = slab_stride;
+}
+
+// C (+ splitk slabs) = A^T B for two k-major operands (amode == bmode == 1), register-direct kernel.
+extern "C" int sca_gemm_kk_f32(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                               int splitk, long long slab_stride, void* stream) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0 || splitk < 1 || lda < M || ldb < N || ldc < N) return -1;
+    if (!kk_shape_ok(A, lda, B, ldb, M, N)) return -2;
+    KKArgs a;
+    fill_kk(a, A, lda, B, ldb, C, ldc, M, N, K, splitk, slab_stride);
+    static const hipError_t attr = hipFuncSetAttribute((const void*)gemm_kk_kernel,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)KK_LDS_BYTES);
+    if (attr != hipSuccess) return (int)attr;
+    hipLaunchKernelGGL(gemm_kk_kernel, dim3(a.tiles_m * a.tiles_n, 1, splitk), dim3(256), KK_LDS_BYTES,
+                       (hipStream_t)stream, a);
+    SCA_CHECK_LAUNCH();
+    return 0;
+}
 
 template <int AM, int BMD, int WM, int WN>
 static void launch_gemm(const GemmArgs& a, dim3 grid, bool vec, hipStream_t st) {

@@ -37,7 +37,7 @@ class _Layer:
         self.bn = bn        # state-dict prefix of the BatchNorm1d after this Linear (use_bn), e.g. "encoder.FC.N0"
 
 
-_QUERIES = {"sca_mid_max_width", "sca_grad_tail_max_jobs", "sca_gemm_group_max_jobs", "sca_gemm_splitk_heuristic", "sca_mmd_num_slabs", "sca_mmd_num_partials", "sca_hsic_workspace_floats",
+_QUERIES = {"sca_gemm_kk_supported", "sca_gemm_kk_splitk_heuristic", "sca_mid_max_width", "sca_grad_tail_max_jobs", "sca_gemm_group_max_jobs", "sca_gemm_splitk_heuristic", "sca_mmd_num_slabs", "sca_mmd_num_partials", "sca_hsic_workspace_floats",
             "sca_proto_workspace_bytes", "sca_abi_version", "sca_device_name"}
 
 
@@ -73,10 +73,16 @@ def _recon_rows_per_block(B):
 class CVAEEngine:
     """Forward / backward / Adam of a trVAE-style conditional VAE on one MI355X."""
 
+    # weight-gradient GEMMs with at least this many output elements take the register-direct k-major kernel (one
+    # workgroup per CU); smaller ones stay in the grouped launch of the LDS-staged kernel
+    KK_MIN_MN = int(os.environ.get("SCA_GEMM_KK_MIN_MN", 65536))
+
     def __init__(self, spec: dict, named_params: "OrderedDict[str, torch.Tensor]", device):
         self._rec = None
         self._ws_gen = 0
         self._plans = {}
+        self._adam_after_tail = None    # (weight_decay, wd_overrides): train_step on one device queues Adam on the aux stream
+        self._adam_done = False
         self._mid_max_split = None      # optional split-K cap of the two GEMMs whose slabs the fused kernels sum
         self.lib = _RecordingLib(_lib.load(), self)
         self.device = torch.device(device)
@@ -279,7 +285,9 @@ class CVAEEngine:
         self.Bcap = 0
         # side stream: MMD runs beside the decoder, every dW / bias / condition-weight gradient beside the dX chain
         self.aux = torch.cuda.Stream(device=self.device)
-        self._events = [torch.cuda.Event() for _ in range(64)]
+        self.aux2 = torch.cuda.Stream(device=self.device)      # output-layer weight gradient beside the dX chain
+        self._lanes_used = set()
+        self._events = [torch.cuda.Event() for _ in range(128)]
         self._ev_i = 0
         self._aux_q = []
         self._rec = None                # launch-plan recorder (train_step)
@@ -484,33 +492,50 @@ class CVAEEngine:
             self._rec.append((fn, args, False))
         return fn(*args)
 
-    def _defer(self, fn):
-        """Side work for the aux stream that depends on everything enqueued on the main stream so far.  The
-        dependency point (an event) is taken now, the launches are issued at the next _flush(): the host keeps
-        feeding the critical main-stream chain first, the aux stream fills in behind it."""
+    def _defer(self, fn, lane=0, join=()):
+        """Side work for an aux stream (lane 0: self.aux, lane 1: self.aux2) that depends on everything enqueued on
+        the main stream so far.  The dependency point (an event) is taken now, the launches are issued at the next
+        _flush(): the host keeps feeding the critical main-stream chain first, the aux streams fill in behind it.
+        `join`: lanes whose work queued BEFORE this entry must also have finished (e.g. the gradient tail on lane 0
+        sums the slabs of a GEMM that ran on lane 1)."""
         if not self.overlap:
             fn(torch.cuda.current_stream(self.device).cuda_stream)
             return
         ev = self._next_event()
         self._call(ev.record, torch.cuda.current_stream(self.device))
-        self._aux_q.append((ev, fn))
+        self._aux_q.append((ev, fn, lane, tuple(join)))
+
+    def _lane_stream(self, lane):
+        return self.aux if lane == 0 else self.aux2
 
     def _flush(self):
-        """Issue the deferred aux-stream work; returns an event marking its end on the aux stream."""
+        """Issue the deferred aux-stream work; returns the events marking its end on the aux streams used so far in
+        this step (None without overlap)."""
         if not self.overlap:
             return None
-        for ev, fn in self._aux_q:
-            self._call(self.aux.wait_event, ev)
-            fn(self.aux.cuda_stream)
+        for ev, fn, lane, join in self._aux_q:
+            stream = self._lane_stream(lane)
+            self._call(stream.wait_event, ev)
+            for other in join:
+                if other != lane and other in self._lanes_used:
+                    ev2 = self._next_event()
+                    self._call(ev2.record, self._lane_stream(other))
+                    self._call(stream.wait_event, ev2)
+            self._lanes_used.add(lane)
+            fn(stream.cuda_stream)
         self._aux_q = []
-        ev = self._next_event()
-        self._call(ev.record, self.aux)
-        return ev
+        evs = []
+        for lane in sorted(self._lanes_used):
+            ev = self._next_event()
+            self._call(ev.record, self._lane_stream(lane))
+            evs.append(ev)
+        return tuple(evs)
 
-    def _wait(self, ev):
-        """main stream waits for an aux-stream event returned by _flush()."""
-        if ev is not None:
-            self._call(torch.cuda.current_stream(self.device).wait_event, ev)
+    def _wait(self, evs):
+        """main stream waits for the aux-stream events returned by _flush()."""
+        if evs is not None:
+            for ev in evs:
+                self._call(torch.cuda.current_stream(self.device).wait_event, ev)
 
     def _zero(self, t, st):
         _lib.check(self.lib.sca_fill_zero(t.data_ptr(), t.numel() * t.element_size(), st), "fill_zero")
@@ -544,7 +569,9 @@ class CVAEEngine:
         """Re-issue recorded GEMM launches (bench.py roofline leg: same shapes, same buffers, nothing else)."""
         st = torch.cuda.current_stream(self.device).cuda_stream
         for args in calls:
-            if args[0] == "group":
+            if args[0] == "kk":
+                _lib.check(self.lib.sca_gemm_kk_f32(*args[1], st), "gemm_kk")
+            elif args[0] == "group":
                 _lib.check(self.lib.sca_gemm_group_f32(args[1], len(args[1]), st), "gemm_group")
             else:
                 _lib.check(self.lib.sca_gemm_f32(*args, st), "gemm")
@@ -561,8 +588,28 @@ class CVAEEngine:
         """Weight-gradient GEMM into `dst` [M, N]: split-K slabs go to a region of their own and their sum becomes a
         job of the tail kernel (instead of a sca_splitk_reduce launch per tensor)."""
         L = self.lib
-        S = L.sca_gemm_splitk_heuristic(M, N, K)
         rec = getattr(self, "record_gemms", None)
+        # large dY^T X products: the register-direct k-major kernel (gemm_f32.hip, gemm_kk_kernel), one launch each
+        if (am == 1 and bm == 1 and M * N >= self.KK_MIN_MN and K >= 1024
+                and L.sca_gemm_kk_supported(A, lda, Bm, ldb, M, N)):
+            S = L.sca_gemm_kk_splitk_heuristic(M, N, K)
+            if S == 1:
+                out, stride = dst.data_ptr(), 0
+            else:
+                key = "gslab:%d" % dst.data_ptr()
+                slab = self.ws.get(key)
+                if slab is None or slab.numel() < S * M * N:
+                    if slab is not None:
+                        self._invalidate()
+                    slab = self.ws[key] = torch.empty(S * M * N, dtype=torch.float32, device=self.device)
+                out, stride = slab.data_ptr(), M * N
+                self._tail_jobs.append((0, S, M * N, out, dst.data_ptr(), M * N, 0, 0, 0, 0, 0))
+            args = (A, lda, Bm, ldb, out, N, M, N, K, S, stride)
+            if rec is not None:
+                rec.append(("kk", args))
+            _lib.check(L.sca_gemm_kk_f32(*args, st), "gemm_kk")
+            return
+        S = L.sca_gemm_splitk_heuristic(M, N, K)
         if S == 1:
             args = (am, bm, A, lda, Bm, ldb, dst.data_ptr(), N, M, N, K, 1, 0, None)
             if rec is not None:
@@ -621,6 +668,15 @@ class CVAEEngine:
             return
         self._tail_jobs.append((1, 0, 0, da, db or 0, 0, dWc or 0, (cond_p or 0) if dWc else 0, B, H,
                                 C if dWc else 0))
+
+    def _defer_tail(self, join=()):
+        """Gradient tail on lane 0 and - single-device train_step - Adam right behind it on the same stream (no
+        cross-stream hop between the last reduction and the update)."""
+        self._defer(self._run_tail, join=join)
+        fused = self._adam_after_tail
+        if fused is not None:
+            self._defer(lambda sa: self.adam_step(fused[0], fused[1], stream=sa))
+            self._adam_done = True
 
     def _run_tail(self, st):
         jobs, self._tail_jobs = self._tail_jobs, []
@@ -709,6 +765,7 @@ class CVAEEngine:
                                              ws["x"].data_ptr(), G, ws["sf"].data_ptr(), st), "csr_gather")
 
         self._aux_q = []
+        self._lanes_used = set()
         self._tail_jobs = []
         self._prologue(B, compute_grad)
         self._covs_cur = covs
@@ -980,7 +1037,7 @@ class CVAEEngine:
                                                  st)
         if self.cond_embed and any(T[k] for (k, _, _) in self.emb):
             self._defer(lambda sa: self._embed_scatter(B, sa))
-        self._defer(self._run_tail)
+        self._defer_tail()
         self._wait(self._flush())
 
     # ------------------------------------------------------------------------------------------ fused middle
@@ -1068,12 +1125,12 @@ class CVAEEngine:
         dl = ws["logits"].data_ptr()
 
         def recon_side(sa):
+            if T[self.out_w]:
+                self._grad_gemm(1, 1, dl, G, h_last, Hd, G, Hd, B, sa, Gd[self.out_w])
             if self.recon != "mse" and T["theta"]:
                 _lib.check(L.sca_transpose_scale(ws["dthetaT"].data_ptr(), max(C, 1), G, -1.0 / B,
                                                  Gd["theta"].data_ptr(), sa), "transpose_scale")
-            if T[self.out_w]:
-                self._grad_gemm(1, 1, dl, G, h_last, Hd, G, Hd, B, sa, Gd[self.out_w])
-        self._defer(recon_side)
+        self._defer(recon_side, lane=1)         # own stream: starts right behind the likelihood kernel
         sp, S, stride = self._gemm(0, 1, dl, G, P[self.out_w].data_ptr(), Hd, B, Hd, G, st, max_split=self._mid_max_split)
         if do_mmd:
             self._wait(ev_side)
@@ -1104,17 +1161,23 @@ class CVAEEngine:
         self._layer_backward(self.enc[0], ws["x"].data_ptr(), None, 0, 0, None, False, B, cond_p, p_drop, masks, st,
                              have_da=True, side_out=sides)
 
-        def weight_side(sa):      # every dY^T X of the encoder / middle layers: ONE grouped GEMM launch
+        def weight_side(sa):      # the wide first-layer dY^T X: register-direct kernel on the aux stream
             self._gg_jobs = []
             try:
                 for f in sides:
-                    f(sa)         # the wide first-layer GEMM first: its tiles fill the chip, the small ones tuck in
-                mid_side(sa)
+                    f(sa)
             finally:
                 jobs, self._gg_jobs = self._gg_jobs, None
-            self._launch_group(jobs, sa)
+            self._launch_group(jobs, sa)        # (only when the first layer did not qualify for the kk kernel)
         self._defer(weight_side)
-        self._defer(self._run_tail)
+        # ... and beside it, on the main stream (idle after mid_bwd), ONE grouped launch for every narrow layer
+        self._gg_jobs = []
+        try:
+            mid_side(st)
+        finally:
+            jobs, self._gg_jobs = self._gg_jobs, None
+        self._launch_group(jobs, st)
+        self._defer_tail(join=(1,))
         self._wait(self._flush())
         return self.losses
 
@@ -1283,12 +1346,12 @@ class CVAEEngine:
                 open_wd = wd
         return [(s, e, wd) for s, e, wd in merged]
 
-    def adam_step(self, weight_decay=0.04, wd_overrides: Optional[Dict[str, float]] = None):
+    def adam_step(self, weight_decay=0.04, wd_overrides: Optional[Dict[str, float]] = None, stream=None):
         """One torch.optim.Adam-equivalent update of every trainable tensor; hyper[] must hold lr / bias corrections
         for step t = self.adam_t + 1 (call begin_step first).  wd_overrides: per-tensor weight decay (scPoli keeps its
         embeddings in a weight_decay=0 parameter group, trainers/scpoli/trainer.py:297-305)."""
         L = self.lib
-        st = torch.cuda.current_stream(self.device).cuda_stream
+        st = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
         for s, e, wd in self.trainable_ranges(weight_decay, wd_overrides):
             _lib.check(L.sca_adam_step(self.flat_p[s:].data_ptr(), self.flat_g[s:].data_ptr(),
                                        self.flat_m[s:].data_ptr(), self.flat_v[s:].data_ptr(), e - s,
@@ -1431,11 +1494,11 @@ class CVAEEngine:
             use_graph = False
         if use_graph is False:
             self.begin_step(alpha_kl, lr, eps, clip)
-            self.forward_backward(row_ids, cond, B)
+            self._step_and_adam(row_ids, cond, B, weight_decay, wd_overrides, world > 1)
             if world > 1:
                 from . import distributed as sdist
                 sdist.allreduce_mean_(self.flat_g, world, weight=grad_weight)
-            self.adam_step(weight_decay, wd_overrides)
+                self.adam_step(weight_decay, wd_overrides)
             return self.losses
         def plan_key():
             return (B, use_graph is True, float(weight_decay), tuple(sorted((wd_overrides or {}).items())), world > 1,
@@ -1474,6 +1537,18 @@ class CVAEEngine:
                 self._replay(g["adam"])
         return self.losses
 
+    def _step_and_adam(self, rows, cond, B, weight_decay, wd_overrides, split):
+        """forward + backward and - unless a gradient all-reduce sits between them (`split`) - Adam, queued right
+        behind the gradient tail on the aux stream."""
+        self._adam_after_tail = None if split else (weight_decay, wd_overrides)
+        self._adam_done = False
+        try:
+            self.forward_backward(rows, cond, B)
+        finally:
+            self._adam_after_tail = None
+        if not split and not self._adam_done:       # paths without a deferred tail (overlap off)
+            self.adam_step(weight_decay, wd_overrides)
+
     @staticmethod
     def _replay(plan):
         for fn, args, checked in plan:
@@ -1489,8 +1564,7 @@ class CVAEEngine:
         cond = torch.zeros(B, dtype=torch.int32, device=self.device)
         snap = (self.flat_p.clone(), self.flat_m.clone(), self.flat_v.clone(), self.accum.clone(),
                 {k: v.clone() for k, v in self.buffers.items()})
-        self.forward_backward(rows, cond, B)
-        self.adam_step(weight_decay, wd_overrides)
+        self._step_and_adam(rows, cond, B, weight_decay, wd_overrides, False)
         torch.cuda.synchronize(self.device)
         return rows, cond, snap
 
@@ -1506,11 +1580,13 @@ class CVAEEngine:
         out = dict(rows=rows, cond=cond)
         self._rec = []
         try:
-            self.forward_backward(rows, cond, B)
+            self._step_and_adam(rows, cond, B, weight_decay, wd_overrides, split)
             if split:
                 out["fwd"], self._rec = self._rec, []
-            self.adam_step(weight_decay, wd_overrides)
-            out["adam" if split else "fwd"] = self._rec
+                self.adam_step(weight_decay, wd_overrides)
+                out["adam"] = self._rec
+            else:
+                out["fwd"] = self._rec
         finally:
             self._rec = None
         self._restore(snap)
@@ -1526,9 +1602,7 @@ class CVAEEngine:
         out = dict(rows=rows, cond=cond)
         gf = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gf):
-            self.forward_backward(rows, cond, B)
-            if not split:
-                self.adam_step(weight_decay, wd_overrides)
+            self._step_and_adam(rows, cond, B, weight_decay, wd_overrides, split)
         out["fwd"] = gf
         if split:
             ga = torch.cuda.CUDAGraph()

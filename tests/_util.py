@@ -69,7 +69,8 @@ def grads_close(got: dict, ref: dict, rtol=1e-5, floor_frac=0.0, ref64: dict = N
     """Per-tensor max-norm comparison at the north-star tolerance: |got - ref| <= rtol * scale + k_noise * noise, where
     `ref` is the reference's fp32 result, noise = max |ref - ref64| is the reference's own distance from the fp64
     yardstick (measured, 0 when no yardstick is given) and scale = max |ref|.  floor_frac (x the largest gradient
-    entry of the whole model) is a last resort for mathematically-zero tensors when no yardstick is available.
+    entry of the whole model) covers mathematically-zero tensors (a bias in front of BatchNorm: both sides hold pure
+    rounding residue of the order 1e-8 x the model's gradient scale, in an order that float atomics do not fix).
     With `tag` the achieved errors are printed next to the yardstick."""
     gmax = max(float(np.max(np.abs(v))) for v in ref.values())
     bad = []

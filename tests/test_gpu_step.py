@@ -57,7 +57,7 @@ def test_step_losses_and_grads(name):
     got = {k: eng.g[k].cpu().numpy() for k in eng.names}
     # north_star tolerance: rel 1e-5 per gradient tensor, plus twice the reference's own fp32 distance from the fp64
     # yardstick (measured on this case; tests/_util.py grads_close)
-    bad = grads_close(got, Gr, rtol=1e-5, ref64=golden_ref64(name)[1], tag=name)
+    bad = grads_close(got, Gr, rtol=1e-5, floor_frac=1e-7, ref64=golden_ref64(name)[1], tag=name)
     assert not bad, bad
 
 
