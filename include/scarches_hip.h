@@ -110,17 +110,31 @@ int sca_latent_bwd(const float* dz, int S, long long slab_stride, const float* d
  * into dthetaT[C][G] and the output-bias gradients into dbias[G] (both must be zeroed by the caller).
  * cond_off (optional, [C][G]): per-condition offsets added to the logits on load - expiMap's single-layer decoder adds
  * cond_L.weight[:, c_b] right before the softmax (models/expimap/modules.py:83-84, 142).
- * sca_mse_rows: ReLU head (relu=1, trvae.py:125-127) or identity head (relu=0, expimap.py:182-184) + sum of squares.
+ * row_dsf (optional, [B]): d recon / d sizefactor_b - expiMap's library-size encoder makes the size factor a function of
+ * the parameters (models/expimap/expimap.py:164-171,186-187).
+ * sca_mse_rows: sum of squares behind an output activation `relu` = 0 identity (expimap.py:182-184), 1 ReLU
+ * (trvae.py:125-127), 2 softplus, 3 exp (MaskedLinearDecoder last layers, models/expimap/modules.py:119-127).
+ * sca_nb_elem_rows: NB log-likelihood on an elementwise mean mu = act(lin (+ cond_off)) without softmax / size factor
+ * (expiMap with decoder_last_layer in {identity, relu, softplus, exp}: expimap.py:188-196, losses.py:63-102), counts from
+ * CSR; d recon / d lin in place, theta gradients accumulated into dthetaT like sca_recon_rows.
  * sca_transpose_scale: dst[cols][rows] = scale * src[rows][cols] (dthetaT -> theta.grad layout [G][C]). */
 int sca_theta_prep(const float* theta, int G, int C, float* tab_theta, float* tab_lte, void* stream);
 int sca_recon_rows(int zinb, float* logits, int ldl, float* pi, const int64_t* indptr, const int32_t* indices,
                    const float* data, const int64_t* row_ids, const float* sizefactor, const int32_t* cond,
                    const float* tab_theta, const float* tab_lte, int B, int G, int C, int rows_per_block, float* row_ll,
                    float* dthetaT, float* dbias, float* dbias_pi, int compute_grad, const float* cond_off,
-                   void* stream);
+                   float* row_dsf, void* stream);
+int sca_nb_elem_rows(int act, float* lin, int ldl, const int64_t* indptr, const int32_t* indices, const float* data,
+                     const int64_t* row_ids, const int32_t* cond, const float* tab_theta, const float* tab_lte, int B,
+                     int G, int C, int rows_per_block, float* row_ll, float* dthetaT, int compute_grad,
+                     const float* cond_off, void* stream);
 int sca_mse_rows(float* lin, int ldl, const float* x, int ldx, int B, int G, int rows_per_block, float* row_loss,
                  float* dbias, int compute_grad, int relu, const int32_t* cond, const float* cond_off, void* stream);
 int sca_transpose_scale(const float* src, int rows, int cols, float scale, float* dst, void* stream);
+/* Elementwise helpers of expiMap's library-size encoder path (models/expimap/expimap.py:186-187): the size factor is
+ * exp(sampled library latent) (sca_exp_f32) and its gradient chains through a product (sca_mul_f32: dst = a * b). */
+int sca_exp_f32(const float* src, float* dst, long long n, void* stream);
+int sca_mul_f32(const float* a, const float* b, float* dst, long long n, void* stream);
 
 /* ---- MMD -----------------------------------------------------------------------------------------------------
  * Multi-scale RBF MMD between condition blocks (models/trvae/losses.py:166-270, _utils.py:18-24), forward value as

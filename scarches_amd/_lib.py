@@ -76,9 +76,12 @@ SIGNATURES = {
     "sca_latent_fwd": [P, I, LL, P, I, I, P, U64, U32, P, I, P, P, P, P, P],
     "sca_latent_bwd": [P, I, LL, P, I, LL, P, P, P, I, I, P, P],
     "sca_theta_prep": [P, I, I, P, P, P],
-    "sca_recon_rows": [I, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, I, P, P],
+    "sca_recon_rows": [I, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, I, P, P, P],
+    "sca_nb_elem_rows": [I, P, I, P, P, P, P, P, P, P, I, I, I, I, P, P, I, P, P],
     "sca_mse_rows": [P, I, P, I, I, I, I, P, P, I, I, P, P, P],
     "sca_transpose_scale": [P, I, I, F, P, P],
+    "sca_exp_f32": [P, P, LL, P],
+    "sca_mul_f32": [P, P, P, LL, P],
     "sca_mmd_num_slabs": [I, I],
     "sca_mmd_num_partials": [I, I],
     "sca_mmd_fwd_bwd": [P, I, P, I, I, I, I, F, P, P, P, P, LL, P],

@@ -17,3 +17,30 @@ extern "C" int sca_device_name(char* name, int len) {
     }
     return 0;
 }
+
+// Small elementwise helpers of the library-size encoder path of expiMap (models/expimap/expimap.py:186-187):
+// dst = exp(src) (size factor = exp of the sampled library latent) and dst = a * b (chain rule through it).
+namespace {
+__global__ void exp_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = expf(src[i]);
+}
+__global__ void mul_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ dst,
+                           long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = a[i] * b[i];
+}
+}  // namespace
+
+extern "C" int sca_exp_f32(const float* src, float* dst, long long n, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(exp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+extern "C" int sca_mul_f32(const float* a, const float* b, float* dst, long long n, void* stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mul_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, dst, n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}

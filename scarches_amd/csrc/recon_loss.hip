@@ -59,6 +59,8 @@ struct ReconArgs {
     int compute_grad;
     const float* cond_off;          // optional [C][G]: per-condition logit offsets added on load (expiMap's
                                     // decoder.L0.cond_L, scarches/models/expimap/modules.py:83-84), transposed
+    float* row_dsf;                 // optional [B]: d recon / d sizefactor_b (expiMap's library-size encoder makes the
+                                    // size factor a function of the parameters, expimap.py:186-187)
 };
 
 // ---- gamma-function terms of one stored count ---------------------------------------------------------------
@@ -342,7 +344,12 @@ __global__ __launch_bounds__(T, 4) void recon_rows_kernel(const ReconArgs a) {
             for (int i = 0; i < NW; ++i) { ll += red[par][0][i]; Tsum += red[par][1][i]; }
             par ^= 1;
         }
-        if (t == 0) { a.row_ll[b] = ll; qn = 0; }
+        if (t == 0) {
+            a.row_ll[b] = ll;
+            qn = 0;
+            // recon = -sum ll / B and mu = gamma s: d recon / d s = -(1/B) sum_g gamma dll/dmu = -T / (s B)
+            if (a.row_dsf) a.row_dsf[b] = s > 0.f ? -Tsum * invB / s : 0.f;
+        }
 
         if (a.compute_grad) {
 #pragma unroll
@@ -388,12 +395,22 @@ __global__ __launch_bounds__(T, 4) void recon_rows_kernel(const ReconArgs a) {
     }
 }
 
-// MSE head: out = relu(lin) (trVAE recon_decoder) or out = lin (+ per-condition offset; expiMap identity last layer,
-// scarches/models/expimap/expimap.py:182-184), loss_b = sum_g (out - x)^2 ; d lin = 2 (out - x) / B where active.
+// Output activations of the non-softmax heads (MaskedLinearDecoder.mean_decoder, models/expimap/modules.py:119-127;
+// trVAE recon_decoder ReLU, models/trvae/modules.py:172-173): 0 identity, 1 relu, 2 softplus (beta 1, threshold 20), 3 exp.
+__device__ __forceinline__ void head_act(int act, float l, float& o, float& d) {
+    if (act == 1) { o = fmaxf(l, 0.f); d = l > 0.f ? 1.f : 0.f; }
+    else if (act == 2) { o = softplus_t(l); d = l > 20.f ? 1.f : sigmoid_f(l); }
+    else if (act == 3) { o = expf(l); d = o; }
+    else { o = l; d = 1.f; }
+}
+
+// MSE head: out = act(lin (+ per-condition offset)) - relu for the trVAE recon_decoder, identity / relu / softplus / exp
+// for expiMap's last layer (scarches/models/expimap/expimap.py:182-184) - loss_b = sum_g (out - x)^2,
+// d lin = 2 (out - x) act'(lin) / B.
 __global__ __launch_bounds__(256) void mse_rows_kernel(float* __restrict__ lin, int ldl, const float* __restrict__ x,
                                                        int ldx, int B, int G, int rows_per_block,
                                                        float* __restrict__ row_loss, float* __restrict__ dbias,
-                                                       int compute_grad, int relu, const int32_t* __restrict__ cond,
+                                                       int compute_grad, int act, const int32_t* __restrict__ cond,
                                                        const float* __restrict__ cond_off) {
     __shared__ float red[16];
     const int b0 = blockIdx.x * rows_per_block, b1 = min(B, b0 + rows_per_block);
@@ -406,11 +423,12 @@ __global__ __launch_bounds__(256) void mse_rows_kernel(float* __restrict__ lin, 
             if (g < G) {
                 float l = lin[(long long)b * ldl + g];
                 if (cond_off) l += cond_off[(long long)cond[b] * G + g];
-                const float o = relu ? fmaxf(l, 0.f) : l;
+                float o, dv;
+                head_act(act, l, o, dv);
                 const float d = o - x[(long long)b * ldx + g];
                 sq = d * d;
                 if (compute_grad) {
-                    const float dl = (!relu || l > 0.f) ? 2.0f * d * invB : 0.f;
+                    const float dl = 2.0f * d * dv * invB;
                     lin[(long long)b * ldl + g] = dl;
                     accb += dl;
                 }
@@ -422,6 +440,79 @@ __global__ __launch_bounds__(256) void mse_rows_kernel(float* __restrict__ lin, 
             }
         }
         if (compute_grad && dbias && g < G) atomicAdd(&dbias[g], accb);
+    }
+}
+
+// NB likelihood on an ELEMENTWISE mean mu = act(lin) (expiMap with decoder_last_layer in {softplus, exp, relu,
+// identity}: no softmax, no size factor - models/expimap/expimap.py:188-196, losses.py:63-102).  A workgroup walks
+// rows_per_block rows; the row's counts are scattered from CSR into an LDS row, the dense sweep evaluates the full
+// formula (lgamma / digamma only where x > 0), d lin = -(dll/dmu) act'(lin) / B is written in place and the theta
+// gradient theta dll/dtheta is accumulated in LDS over a condition run and flushed with atomics.
+__global__ __launch_bounds__(256) void nb_elem_rows_kernel(const ReconArgs a, int act) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xr = lds;             // [G] counts of the current row
+    float* dth = lds + a.G;      // [G] theta gradient of the current condition run
+    __shared__ float red[16];
+    const int G = a.G, t = threadIdx.x;
+    for (int i = t; i < 2 * G; i += 256) lds[i] = 0.f;
+    const int b0 = blockIdx.x * a.rows_per_block, b1 = min(a.B, b0 + a.rows_per_block);
+    const float invB = 1.0f / (float)a.B;
+    __syncthreads();
+    for (int b = b0; b < b1; ++b) {
+        const int64_t r = a.row_ids ? a.row_ids[b] : (int64_t)b;
+        const int64_t ks = a.indptr[r], ke = a.indptr[r + 1];
+        const int c = a.cond ? a.cond[b] : 0;
+        for (int64_t k = ks + t; k < ke; k += 256) xr[a.indices[k]] = a.data[k];
+        __syncthreads();
+        float* lrow = a.logits + (long long)b * a.ldl;
+        const float* tth = a.tab_theta + (long long)c * G;
+        const float* tlt = a.tab_lte + (long long)c * G;
+        const float* coff = a.cond_off ? a.cond_off + (long long)c * G : nullptr;
+        float ll = 0.f;
+        for (int g = t; g < G; g += 256) {
+            const float l = lrow[g] + (coff ? coff[g] : 0.f);
+            float mu, dmu;
+            head_act(act, l, mu, dmu);
+            const float x = xr[g], th = tth[g], lte = tlt[g];
+            xr[g] = 0.f;
+            const float den = th + mu + NB_EPS;
+            const float L = logf(den), rr = 1.0f / den;
+            float v = th * (lte - L);
+            float dll_dmu = -th * rr;
+            float thd = th * (lte - L + th / (th + NB_EPS) - th * rr);     // theta dll/dtheta
+            if (x > 0.f) {
+                float lgam, dig;
+                if (nb_gamma_fast_ok(x, th)) {
+                    const int n = min((int)x, 16);
+                    float num = 0.f, dn = 1.f, fact = 1.f, f = th, fq = 1.f;
+                    for (int q = 0; q < n; ++q) { num = fmaf(num, f, dn); dn *= f; fact *= fq; f += 1.0f; fq += 1.0f; }
+                    const float rden = 1.0f / dn;
+                    dig = num * rden;
+                    lgam = -logf(fact * rden);
+                } else {
+                    nb_gamma_terms_heavy(x, th, &lgam, &dig);
+                }
+                v += x * (logf(mu + NB_EPS) - L) + lgam;
+                dll_dmu += x * (1.0f / (mu + NB_EPS) - rr);
+                thd += th * (-x * rr + dig);
+            }
+            ll += v;
+            if (a.compute_grad) {
+                lrow[g] = -dll_dmu * dmu * invB;
+                dth[g] += thd;
+            }
+        }
+        ll = block_sum(ll, red);
+        if (t == 0) a.row_ll[b] = ll;
+        const bool flush = a.compute_grad && a.dthetaT && (b + 1 == b1 || (a.cond && a.cond[b + 1] != c));
+        if (flush) {
+            float* dst = a.dthetaT + (long long)c * G;
+            for (int g = t; g < G; g += 256) {
+                atomicAdd(&dst[g], dth[g]);
+                dth[g] = 0.f;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -471,14 +562,33 @@ extern "C" int sca_recon_rows(int zinb, float* logits, int ldl, float* pi, const
                               const float* sizefactor, const int32_t* cond, const float* tab_theta,
                               const float* tab_lte, int B, int G, int C, int rows_per_block, float* row_ll,
                               float* dthetaT, float* dbias, float* dbias_pi, int compute_grad,
-                              const float* cond_off, void* stream) {
+                              const float* cond_off, float* row_dsf, void* stream) {
     if (B <= 0) return 0;
     if (rows_per_block < 1 || ldl < G) return -1;
     if (cond_off && !cond) return -1;
     ReconArgs a{logits, ldl, pi, indptr, indices, data, row_ids, sizefactor, cond, tab_theta, tab_lte,
-                B, G, C, rows_per_block, row_ll, dthetaT, dbias, dbias_pi, compute_grad, cond_off};
+                B, G, C, rows_per_block, row_ll, dthetaT, dbias, dbias_pi, compute_grad, cond_off, row_dsf};
     const int rc = zinb ? launch_recon<true>(a, (hipStream_t)stream) : launch_recon<false>(a, (hipStream_t)stream);
     if (rc) return rc;
+    SCA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sca_nb_elem_rows(int act, float* lin, int ldl, const int64_t* indptr, const int32_t* indices,
+                                const float* data, const int64_t* row_ids, const int32_t* cond,
+                                const float* tab_theta, const float* tab_lte, int B, int G, int C, int rows_per_block,
+                                float* row_ll, float* dthetaT, int compute_grad, const float* cond_off, void* stream) {
+    if (B <= 0) return 0;
+    if (rows_per_block < 1 || ldl < G || act < 0 || act > 3) return -1;
+    if (cond_off && !cond) return -1;
+    const size_t shm = (size_t)2 * G * sizeof(float);
+    if (shm > 150 * 1024) return -2;
+    ReconArgs a{lin, ldl, nullptr, indptr, indices, data, row_ids, nullptr, cond, tab_theta, tab_lte,
+                B, G, C, rows_per_block, row_ll, dthetaT, nullptr, nullptr, compute_grad, cond_off, nullptr};
+    if (shm > 48 * 1024)
+        hipFuncSetAttribute((const void*)nb_elem_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipLaunchKernelGGL(nb_elem_rows_kernel, dim3((B + rows_per_block - 1) / rows_per_block), dim3(256), shm,
+                       (hipStream_t)stream, a, act);
     SCA_CHECK_LAUNCH();
     return 0;
 }
@@ -488,6 +598,7 @@ extern "C" int sca_mse_rows(float* lin, int ldl, const float* x, int ldx, int B,
                             const float* cond_off, void* stream) {
     if (B <= 0) return 0;
     if (cond_off && !cond) return -1;
+    if (relu < 0 || relu > 3) return -1;
     const int nblk = (B + rows_per_block - 1) / rows_per_block;
     hipLaunchKernelGGL(mse_rows_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, lin, ldl, x, ldx, B, G,
                        rows_per_block, row_loss, dbias, compute_grad, relu, cond, cond_off);

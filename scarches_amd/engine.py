@@ -117,12 +117,18 @@ class CVAEEngine:
         self.hsic_beta = float(s.get("hsic_beta", 1.0))
         if self.arch == "expimap":
             assert self.recon in ("nb", "mse")
-            if s.get("use_l_encoder", False):
-                raise NotImplementedError("use_l_encoder=True (library-size encoder) is not built in the HIP path")
+            # MaskedLinearDecoder last layer (models/expimap/modules.py:96-127): softmax (nb default), identity (mse
+            # default), softplus, exp, relu; the non-softmax heads give an elementwise mean without the size factor
             last = s.get("decoder_last_layer") or ("softmax" if self.recon == "nb" else "identity")
-            if (self.recon, last) not in (("nb", "softmax"), ("mse", "identity")):
-                raise NotImplementedError("decoder_last_layer=%r with recon_loss=%r is not built in the HIP path "
-                                          "(softmax+nb and identity+mse are)" % (last, self.recon))
+            if last not in ("softmax", "identity", "relu", "softplus", "exp"):
+                raise ValueError("Unrecognized last layer.")
+            if self.recon == "mse" and last == "softmax":
+                raise ValueError("Can't specify softmax last layer with mse loss.")
+            self.last_layer = last
+            self.last_act = {"identity": 0, "relu": 1, "softplus": 2, "exp": 3}.get(last, -1)
+            # library-size encoder (expimap.py:164-171): only consulted with nb + softmax (expimap.py:186-187)
+            self.use_l_encoder = bool(s.get("use_l_encoder", False))
+            self.lenc_active = self.use_l_encoder and self.recon == "nb" and last == "softmax"
             self.use_mmd = False
         # scPoli: conditions enter as dense embedding vectors (hstack of nn.Embedding lookups, one table per
         # covariate); theta is indexed by the combined condition (scarches/models/scpoli/scpoli.py:99-101,137,161-176)
@@ -146,7 +152,11 @@ class CVAEEngine:
                    + ["encoder.log_var_encoder.weight"] + (["encoder.expand_var_encoder.weight"] if xw else []))
         fused_b = [k[:-6] + "bias" for k in fused_w]
         fused = fused_w + fused_b
-        order = [k for k in order if k not in fused]
+        # expiMap's library-size encoder: its two 1 x 128 heads are stored back to back as well ([2, 128] GEMM)
+        lenc = getattr(self, "lenc_active", False) or getattr(self, "use_l_encoder", False)
+        fused_lw = ["l_encoder.mean_encoder.weight", "l_encoder.log_var_encoder.weight"] if lenc else []
+        fused_lb = [k[:-6] + "bias" for k in fused_lw]
+        order = [k for k in order if k not in fused and k not in fused_lw and k not in fused_lb]
         self.offsets: Dict[str, int] = {}
         self.shapes: Dict[str, tuple] = {}
         off = 0
@@ -154,7 +164,7 @@ class CVAEEngine:
             self.offsets[k] = off
             self.shapes[k] = tuple(named_params[k].shape)
             off = _round_up(off + named_params[k].numel(), ALIGN)
-        for pair in (fused_w, fused_b):
+        for pair in (fused_w, fused_b, fused_lw, fused_lb):
             for k in pair:
                 self.offsets[k] = off
                 self.shapes[k] = tuple(named_params[k].shape)
@@ -261,6 +271,26 @@ class CVAEEngine:
             _expect(k, (self.Zx if "expand" in k else Z, H[-1]))
         for k, n, e in self.emb:
             _expect(k, (n, e))
+        self.lenc = None
+        if lenc:
+            if self.use_bn:
+                raise NotImplementedError("use_l_encoder=True together with use_bn=True is not built in the HIP path")
+            Hl_ = self.shapes["l_encoder.FC.L0.expr_L.weight"][0]       # 128 in the reference (expimap.py:165)
+            self.lenc = _Layer("lenc0", "l_encoder.FC.L0.expr_L.weight", "l_encoder.FC.L0.expr_L.bias",
+                               "l_encoder.FC.L0.cond_L.weight" if has_c else None, G, Hl_, 60, "lenc0")
+            _expect(self.lenc.w, (Hl_, G))
+            _expect(self.lenc.b, (Hl_,))
+            _expect(self.lenc.wc, (Hl_, self.C))
+            for k in fused_lw:
+                _expect(k, (1, Hl_))
+            lw, lb = self.offsets[fused_lw[0]], self.offsets[fused_lb[0]]
+            self.lheads_w = self.flat_p[lw:lw + 2 * Hl_].view(2, Hl_)
+            self.lheads_b = self.flat_p[lb:lb + 2]
+            self.lheads_gw = self.flat_g[lw:lw + 2 * Hl_].view(2, Hl_)
+            self.lheads_gb = self.flat_g[lb:lb + 2]
+            self.lheads_names = fused_lw + fused_lb
+            self.zero_hyper = torch.zeros(8, dtype=torch.float32, device=dev)     # KL weight 0: the library latent
+                                                                                  # carries no KL term (expimap.py:198)
         Zt = self.Zt
         ow, ob = self.offsets[fused_w[0]], self.offsets[fused_b[0]]
         self.heads_w = self.flat_p[ow:ow + 2 * Zt * H[-1]].view(2 * Zt, H[-1])
@@ -337,6 +367,12 @@ class CVAEEngine:
         names = set(names)
         for k in self.names:
             self.trainable[k] = k in names
+        if self.lenc is not None and not self.lenc_active:
+            # an unused library-size encoder (expimap.py:186: only nb + softmax consults it) never receives a
+            # gradient in the reference, so torch's Adam skips it - weight decay included
+            for k in self.names:
+                if k.startswith("l_encoder."):
+                    self.trainable[k] = False
 
     # ------------------------------------------------------------------------------------------ workspaces
     def _invalidate(self):
@@ -411,6 +447,15 @@ class CVAEEngine:
                 def bw(d):          # RBF bandwidth of models/expimap/losses.py:15-21
                     return 1.0 / (2.0 * (2.0 * math.gamma(0.5 * (d + 1)) / math.gamma(0.5 * d)) ** 2)
                 self._hsic_sigmas = [(bw(sd.count(0)), bw(sd.count(1))) for sd in sides]
+        if self.lenc is not None:
+            ly = self.lenc
+            ws["lenc0.yn"] = torch.empty(B, ly.n_out, dtype=f32, device=dev)
+            ws["lenc0.rs"] = torch.empty(B, dtype=f32, device=dev)
+            ws["lenc0.h"] = torch.empty(B, ly.n_out, dtype=f32, device=dev)
+            ws["lenc0.da"] = torch.empty(B, ly.n_out, dtype=f32, device=dev)
+            for k, w in (("l_mu_lv", 2), ("l_eps", 1), ("l_z", 1), ("l_kl", 1), ("sf_l", 1), ("dsf", 1), ("l_dz", 1),
+                         ("l_dheads", 2)):
+                ws[k] = torch.empty(B, w, dtype=f32, device=dev)
         ws["da"] = torch.empty(B, max(Hmax, 2 * Z), dtype=f32, device=dev)
         ws["dheads"] = torch.empty(B, 2 * Z, dtype=f32, device=dev)
         ws["dh0"] = torch.empty(B, H[0], dtype=f32, device=dev)
@@ -425,6 +470,9 @@ class CVAEEngine:
             for ly in self.enc + self.dec:
                 if ly.wc:
                     shapes += [(Bsym, self.E, ly.n_out), (ly.n_out, self.E, Bsym)]
+        if self.lenc is not None:
+            Hl_ = self.lenc.n_out
+            shapes += [(Bsym, Hl_, G), (Hl_, G, Bsym), (Bsym, 2, Hl_), (2, Hl_, Bsym), (Bsym, Hl_, 2)]
         if xp:
             shapes += [(G, Z, Bsym), (Bsym, Z, G)]
         else:
@@ -859,7 +907,7 @@ class CVAEEngine:
                                         ws["dthetaT"].data_ptr(), gob,
                                         self.g["decoder.dropout_decoder.bias"].data_ptr()
                                         if zinb and self.trainable["decoder.dropout_decoder.bias"] else None,
-                                        int(compute_grad), None, st), "recon_rows")
+                                        int(compute_grad), None, None, st), "recon_rows")
             recon_sign = -1.0
         self._defer_finalize(recon_sign, B, accumulate_logs)
         if not compute_grad:
@@ -1115,7 +1163,7 @@ class CVAEEngine:
                                         dv.data_ptr(), ptr(row_ids), ws["sf"].data_ptr(), cond_p,
                                         ws["tab_theta"].data_ptr(), ws["tab_lte"].data_ptr(), B, G, max(C, 1), rpb,
                                         ws["row_ll"].data_ptr(), ws["dthetaT"].data_ptr(), gob, None,
-                                        int(compute_grad), None, st), "recon_rows")
+                                        int(compute_grad), None, None, st), "recon_rows")
             recon_sign = -1.0
         self._defer_finalize(recon_sign, B, accumulate_logs)
         if not compute_grad:
@@ -1275,20 +1323,33 @@ class CVAEEngine:
         self._gemm(0, 0, ws["z"].data_ptr(), Zt, ws["Weff"].data_ptr(), Zt, B, G, Zt, st,
                    out=ws["logits"].data_ptr(), ldc=G, force_s1=True)
         ev_side = self._flush()
+        lenc = self.lenc if self.lenc_active else None
+        sf_p = ws["sf"].data_ptr()
+        if lenc is not None:        # size factor = exp(sampled library latent) (expimap.py:186-187)
+            sf_p = self._lenc_forward(B, cond_p, st)
         self._wait(self._ev_pro)
         rpb = _recon_rows_per_block(B)
         if self.recon == "mse":
             _lib.check(L.sca_mse_rows(ws["logits"].data_ptr(), G, ws["x"].data_ptr(), G, B, G, rpb,
-                                      ws["row_ll"].data_ptr(), None, int(compute_grad), 0, cond_p, coff, st),
-                       "mse_rows")
+                                      ws["row_ll"].data_ptr(), None, int(compute_grad), self.last_act, cond_p, coff,
+                                      st), "mse_rows")
             recon_sign = 1.0
+        elif self.last_layer != "softmax":
+            ip, ix, dv = self.csr
+            _lib.check(L.sca_nb_elem_rows(self.last_act, ws["logits"].data_ptr(), G, ip.data_ptr(), ix.data_ptr(),
+                                          dv.data_ptr(), ptr(row_ids), cond_p, ws["tab_theta"].data_ptr(),
+                                          ws["tab_lte"].data_ptr(), B, G, max(C, 1), rpb, ws["row_ll"].data_ptr(),
+                                          ws["dthetaT"].data_ptr(), int(compute_grad), coff, st), "nb_elem_rows")
+            recon_sign = -1.0
         else:
             ip, ix, dv = self.csr
             _lib.check(L.sca_recon_rows(0, ws["logits"].data_ptr(), G, None, ip.data_ptr(), ix.data_ptr(),
-                                        dv.data_ptr(), ptr(row_ids), ws["sf"].data_ptr(), cond_p,
+                                        dv.data_ptr(), ptr(row_ids), sf_p, cond_p,
                                         ws["tab_theta"].data_ptr(), ws["tab_lte"].data_ptr(), B, G, max(C, 1), rpb,
                                         ws["row_ll"].data_ptr(), ws["dthetaT"].data_ptr(), None, None,
-                                        int(compute_grad), coff, st), "recon_rows")
+                                        int(compute_grad), coff,
+                                        ws["dsf"].data_ptr() if (lenc is not None and compute_grad) else None, st),
+                       "recon_rows")
             recon_sign = -1.0
         self._defer_finalize(recon_sign, B, accumulate_logs)
         if not compute_grad:
@@ -1312,6 +1373,8 @@ class CVAEEngine:
             if self.xp_wc and T[self.xp_wc]:
                 self._colsum(dl, B, G, cond_p, C, Gd[self.xp_wc].data_ptr(), None, sa)
         self._defer(side)
+        if lenc is not None:
+            self._lenc_backward(B, cond_p, st)
         sp, S, stride = self._gemm(0, 1, dl, G, ws["Weff"].data_ptr(), Zt, B, Zt, G, st)
         if self.use_hsic:
             self._wait(ev_side)
@@ -1319,6 +1382,44 @@ class CVAEEngine:
                                       ws["hsic_dz"].data_ptr() if self.use_hsic else None,
                                       1 if self.use_hsic else 0)
         return self.losses
+
+    def _lenc_forward(self, B, cond_p, st):
+        """expiMap library-size encoder (models/expimap/expimap.py:164-171): ExtEncoder([G, 128], 1) on the
+        log-transformed minibatch, sampled like z, size factor = exp(sample) (expimap.py:186-187).  Returns the
+        device pointer of the [B] size factors."""
+        L, P, ws, ly = self.lib, self.p, self.ws, self.lenc
+        masks, p_drop = self._masks_cur, self._p_drop_cur
+        sp, S, stride = self._gemm(0, 0, ws["x"].data_ptr(), ly.n_in, P[ly.w].data_ptr(), ly.n_in, B, ly.n_out, ly.n_in,
+                                   st)
+        h = self._layer_block_fwd(ly, sp, S, stride, B, (self.C, cond_p, None, 0), p_drop,
+                                  _lib.ptr(masks.get(ly.mask_key)), True, self.step_ctr.data_ptr(), st)
+        Hl = ly.n_out
+        self._gemm(0, 0, h, Hl, self.lheads_w.data_ptr(), Hl, B, 2, Hl, st, out=ws["l_mu_lv"].data_ptr(), ldc=2,
+                   bias=self.lheads_b.data_ptr(), force_s1=True)
+        _lib.check(L.sca_latent_fwd(ws["l_mu_lv"].data_ptr(), 1, 0, None, B, 1, _lib.ptr(masks.get("eps_l")), self.seed,
+                                    3, self.step_ctr.data_ptr(), 1, ws["l_mu_lv"].data_ptr(), ws["l_eps"].data_ptr(),
+                                    ws["l_z"].data_ptr(), ws["l_kl"].data_ptr(), st), "latent_fwd[lenc]")
+        _lib.check(L.sca_exp_f32(ws["l_z"].data_ptr(), ws["sf_l"].data_ptr(), B, st), "exp[lenc]")
+        return ws["sf_l"].data_ptr()
+
+    def _lenc_backward(self, B, cond_p, st):
+        """Gradient of the reconstruction loss through the sampled size factor into the library-size encoder: no KL
+        term is attached to that latent (expimap.py:198-202 only penalises z1)."""
+        L, P, Gd, ws, T, ly = self.lib, self.p, self.g, self.ws, self.trainable, self.lenc
+        Hl = ly.n_out
+        _lib.check(L.sca_mul_f32(ws["dsf"].data_ptr(), ws["sf_l"].data_ptr(), ws["l_dz"].data_ptr(), B, st), "mul[lenc]")
+        _lib.check(L.sca_latent_bwd(ws["l_dz"].data_ptr(), 1, B, None, 0, 0, ws["l_mu_lv"].data_ptr(),
+                                    ws["l_eps"].data_ptr(), self.zero_hyper.data_ptr(), B, 1,
+                                    ws["l_dheads"].data_ptr(), st), "latent_bwd[lenc]")
+        dh, h = ws["l_dheads"].data_ptr(), ws["lenc0.h"].data_ptr()
+        if any(T[k] for k in self.lheads_names):
+            def heads_side(sa):
+                self._grad_gemm(1, 1, dh, 2, h, Hl, 2, Hl, B, sa, self.lheads_gw)
+                self._colsum(dh, B, 2, None, 0, None, self.lheads_gb.data_ptr(), sa)
+            self._defer(heads_side)
+        sp, S, stride = self._gemm(0, 1, dh, 2, self.lheads_w.data_ptr(), Hl, B, Hl, 2, st)
+        self._layer_backward(ly, ws["x"].data_ptr(), sp, S, stride, None, False, B, cond_p, self._p_drop_cur,
+                             self._masks_cur, st)
 
     def _scratch_bh(self, B, Hd):
         if not hasattr(self, "_sbh") or self._sbh.numel() < B * Hd:

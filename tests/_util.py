@@ -51,7 +51,8 @@ def golden_ref64(name):
         ext_mask = torch.tensor(z["ext_mask"]) if "ext_mask" in z.files else None
         res, grads, _ = E.expimap_loss_and_grads({k: v for k, v in W.items() if not k.endswith(".mask")}, cfg, x,
                                                  z["batch"], sf, eps, alpha, float(z["beta"]), mask, ext_mask,
-                                                 masks or None, dtype=torch.float64)
+                                                 masks or None, dtype=torch.float64,
+                                                 eps_l=torch.tensor(z["eps_l"]) if "eps_l" in z.files else None)
     elif name.startswith("scpoli"):
         from oracle import scpoli_oracle as S
         res, grads, _ = S.scpoli_loss_and_grads(W, cfg, x, z["batch"], z["combined"], sf, eps, alpha, float(z["eta"]),

@@ -247,7 +247,7 @@ def test_nb_rows_against_oracle(lib):
                                           dev(xs.data).data_ptr(), None, dev(sf).data_ptr(), dev(cond).data_ptr(),
                                           tabt.data_ptr(), tabl.data_ptr(), B, G, C, rpb, row_ll.data_ptr(),
                                           dthT.data_ptr(), db.data_ptr(), dbp.data_ptr() if zinb else None, 1, None,
-                                          st()),
+                                          None, st()),
                        "recon_rows")
             torch.cuda.synchronize()
             assert rel_err(row_ll.cpu().numpy(), ll.sum(-1).detach().numpy()) < 2e-6, (B, G, zinb)
@@ -279,7 +279,7 @@ def test_nb_elementwise_golden(lib):
                                   dev(xs.indices, torch.int32).data_ptr(), dev(xs.data).data_ptr(), None,
                                   dev(sf.astype(np.float32)).data_ptr(), dev(np.arange(B), torch.int32).data_ptr(),
                                   tabt.data_ptr(), tabl.data_ptr(), B, G, B, 1, row_ll.data_ptr(), dthT.data_ptr(),
-                                  None, None, 1, None, st()), "recon_rows")
+                                  None, None, 1, None, None, st()), "recon_rows")
     torch.cuda.synchronize()
     ref = z["nb_ll"].astype(np.float64).sum(1)
     assert rel_err(row_ll.cpu().numpy(), ref) < 1e-5

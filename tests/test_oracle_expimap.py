@@ -10,7 +10,14 @@ from tests._util import GOLDEN, dense_from_case, golden_ref64, grads_close, load
 
 torch.set_num_threads(1)
 TOL = 1e-5
-EXPIMAP_CASES = ["expimap_nb_hard", "expimap_nb_ext", "expimap_mse_soft", "expimap_nb_hsic_ova"]
+EXPIMAP_CASES = ["expimap_nb_hard", "expimap_nb_ext", "expimap_mse_soft", "expimap_nb_hsic_ova",
+                 # decoder last layers other than softmax / identity and the library-size encoder
+                 "expimap_nb_softplus", "expimap_nb_exp", "expimap_nb_relu", "expimap_mse_relu", "expimap_mse_softplus",
+                 "expimap_nb_lenc"]
+
+
+def _eps_l(z):
+    return torch.tensor(z["eps_l"]) if "eps_l" in z.files else None
 
 
 def _params(W):
@@ -30,7 +37,7 @@ def test_expimap_losses_and_grads(name):
     mask, ext_mask = _masks(z, cfg)
     res, grads, aux = E.expimap_loss_and_grads(_params(W), cfg, x, z["batch"], torch.tensor(z["sizefactor"]),
                                                torch.tensor(z["eps"]), float(z["alpha"]), float(z["beta"]), mask,
-                                               ext_mask, masks or None)
+                                               ext_mask, masks or None, eps_l=_eps_l(z))
     assert abs(res["recon"] - float(z["recon"])) <= TOL * abs(float(z["recon"]))
     assert abs(res["kl"] - float(z["kl"])) <= TOL * abs(float(z["kl"]))
     if cfg["use_hsic"]:
@@ -54,7 +61,8 @@ def test_expimap_latent_eval(name):
     assert rel_err((torch.exp(lv) + 1e-4).numpy(), z["z_var"]) < TOL
 
 
-@pytest.mark.parametrize("name", ["expimap_nb_hard", "expimap_nb_ext", "expimap_mse_soft"])
+@pytest.mark.parametrize("name", ["expimap_nb_hard", "expimap_nb_ext", "expimap_mse_soft", "expimap_nb_softplus",
+                                  "expimap_nb_lenc"])
 def test_expimap_adam_prox_steps(name):
     """Adam + proximal operators in the order of expiMapTrainer.on_iteration (regularized.py:283-298)."""
     z, cfg, W, _, masks = load_case(name)
@@ -68,7 +76,8 @@ def test_expimap_adam_prox_steps(name):
     for t in range(1, steps + 1):
         _, grads, _ = E.expimap_loss_and_grads({k: v.numpy() for k, v in P.items()}, cfg, x, z["batch"],
                                                torch.tensor(z["sizefactor"]), torch.tensor(z["eps"]),
-                                               float(z["alpha"]), float(z["beta"]), mask, ext_mask, masks or None)
+                                               float(z["alpha"]), float(z["beta"]), mask, ext_mask, masks or None,
+                                               eps_l=_eps_l(z))
         for k in P:
             O.adam_step(P[k], grads[k], M[k], V[k], t, lr=lr, eps=0.01, wd=wd)
         if cfg["alpha_l1"] is not None and cfg["soft_mask"]:
