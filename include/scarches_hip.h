@@ -124,6 +124,12 @@ int sca_recon_rows(int zinb, float* logits, int ldl, float* pi, const int64_t* i
                    const float* tab_theta, const float* tab_lte, int B, int G, int C, int rows_per_block, float* row_ll,
                    float* dthetaT, float* dbias, float* dbias_pi, int compute_grad, const float* cond_off,
                    float* row_dsf, void* stream);
+/* sca_poisson_rows: scPoli's 'poisson' head (models/scpoli/scpoli.py:189-191,607,640; models/trvae/losses.py:44-60): the
+ * softmax output is the Poisson rate, row_loss[b] = sum_g [rate - xlogy(x, rate) + lgamma(x + 1)] with counts from CSR,
+ * d (sum_b row_loss / B) / d logits written in place; sizefactor[b] = sum_g x_bg. */
+int sca_poisson_rows(float* logits, int ldl, const int64_t* indptr, const int32_t* indices, const float* data,
+                     const int64_t* row_ids, const float* sizefactor, int B, int G, int rows_per_block, float* row_loss,
+                     int compute_grad, void* stream);
 int sca_nb_elem_rows(int act, float* lin, int ldl, const int64_t* indptr, const int32_t* indices, const float* data,
                      const int64_t* row_ids, const int32_t* cond, const float* tab_theta, const float* tab_lte, int B,
                      int G, int C, int rows_per_block, float* row_ll, float* dthetaT, int compute_grad,

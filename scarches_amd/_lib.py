@@ -77,6 +77,7 @@ SIGNATURES = {
     "sca_latent_bwd": [P, I, LL, P, I, LL, P, P, P, I, I, P, P],
     "sca_theta_prep": [P, I, I, P, P, P],
     "sca_recon_rows": [I, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, I, P, P, P],
+    "sca_poisson_rows": [P, I, P, P, P, P, P, I, I, I, P, I, P],
     "sca_nb_elem_rows": [I, P, I, P, P, P, P, P, P, P, I, I, I, I, P, P, I, P, P],
     "sca_mse_rows": [P, I, P, I, I, I, I, P, P, I, I, P, P, P],
     "sca_transpose_scale": [P, I, I, F, P, P],

@@ -516,6 +516,53 @@ __global__ __launch_bounds__(256) void nb_elem_rows_kernel(const ReconArgs a, in
     }
 }
 
+// Poisson head of scPoli (models/scpoli/scpoli.py:189-191,607,640; models/trvae/losses.py:44-60): the softmax output is
+// the Poisson rate itself (no size factor), loss_b = sum_g [rate - xlogy(x, rate) + lgamma(x + 1)]
+//   = 1 - sum_nnz x log(gamma_g) + sum_nnz lgamma(x + 1),   d loss / d logit_g = (gamma_g S_b - x_bg) / B,  S_b = sum_g x.
+// One workgroup walks rows_per_block rows; counts come straight from CSR.
+__global__ __launch_bounds__(256) void poisson_rows_kernel(float* __restrict__ logits, int ldl,
+                                                           const int64_t* __restrict__ indptr,
+                                                           const int32_t* __restrict__ indices,
+                                                           const float* __restrict__ data,
+                                                           const int64_t* __restrict__ row_ids,
+                                                           const float* __restrict__ sizefactor, int B, int G,
+                                                           int rows_per_block, float* __restrict__ row_loss,
+                                                           int compute_grad) {
+    __shared__ float red[16];
+    __shared__ double redd[16];
+    const int t = threadIdx.x;
+    const int b0 = blockIdx.x * rows_per_block, b1 = min(B, b0 + rows_per_block);
+    const float invB = 1.0f / (float)B;
+    for (int b = b0; b < b1; ++b) {
+        float* lrow = logits + (long long)b * ldl;
+        const int64_t r = row_ids ? row_ids[b] : (int64_t)b;
+        const int64_t ks = indptr[r], ke = indptr[r + 1];
+        float mx = -INFINITY;
+        for (int g = t; g < G; g += 256) mx = fmaxf(mx, lrow[g]);
+        mx = block_max(mx, red);
+        float se = 0.f;
+        for (int g = t; g < G; g += 256) se += expf(lrow[g] - mx);
+        se = block_sum(se, red);
+        const float lse = mx + logf(se);
+        // stored counts: - x log gamma + lgamma(x + 1), in double (a few hundred terms per row)
+        double acc = 0.0;
+        for (int64_t k = ks + t; k < ke; k += 256) {
+            const float x = data[k];
+            if (x > 0.f) acc += -(double)x * (double)(lrow[indices[k]] - lse) + lgamma((double)x + 1.0);
+        }
+        acc = block_sum_d(acc, redd);
+        if (t == 0) row_loss[b] = (float)(1.0 + acc);
+        if (compute_grad) {
+            const float S = sizefactor[b];
+            __syncthreads();                       // every read of the logits is done
+            for (int g = t; g < G; g += 256) lrow[g] = expf(lrow[g] - lse) * S * invB;
+            __syncthreads();
+            for (int64_t k = ks + t; k < ke; k += 256) lrow[indices[k]] -= data[k] * invB;   // canonical CSR: unique columns
+        }
+        __syncthreads();
+    }
+}
+
 template <bool ZINB>
 int launch_recon(const ReconArgs& a, hipStream_t st) {
     const int G = a.G;
@@ -589,6 +636,18 @@ extern "C" int sca_nb_elem_rows(int act, float* lin, int ldl, const int64_t* ind
         hipFuncSetAttribute((const void*)nb_elem_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     hipLaunchKernelGGL(nb_elem_rows_kernel, dim3((B + rows_per_block - 1) / rows_per_block), dim3(256), shm,
                        (hipStream_t)stream, a, act);
+    SCA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sca_poisson_rows(float* logits, int ldl, const int64_t* indptr, const int32_t* indices,
+                                const float* data, const int64_t* row_ids, const float* sizefactor, int B, int G,
+                                int rows_per_block, float* row_loss, int compute_grad, void* stream) {
+    if (B <= 0) return 0;
+    if (rows_per_block < 1 || ldl < G) return -1;
+    hipLaunchKernelGGL(poisson_rows_kernel, dim3((B + rows_per_block - 1) / rows_per_block), dim3(256), 0,
+                       (hipStream_t)stream, logits, ldl, indptr, indices, data, row_ids, sizefactor, B, G,
+                       rows_per_block, row_loss, compute_grad);
     SCA_CHECK_LAUNCH();
     return 0;
 }

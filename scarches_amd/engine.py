@@ -103,7 +103,9 @@ class CVAEEngine:
         self.boundary = s.get("boundary", None)
         self.beta = float(s.get("beta", 1.0))
         self.seed = int(s.get("seed", 2020))
-        assert self.recon in ("nb", "zinb", "mse")
+        assert self.recon in ("nb", "zinb", "mse", "poisson")
+        # the dispersion parameter theta only exists for the negative-binomial family (trvae.py:89-92, scpoli.py:83-88)
+        self.has_theta = self.recon in ("nb", "zinb")
         assert len(self.H) >= 1, "at least one hidden layer is required"
         # architecture family: "trvae" (MLP decoder, one-hot conditions), "expimap" (single masked linear decoder
         # layer + extension terms, scarches/models/expimap/expimap.py:44-171)
@@ -225,7 +227,7 @@ class CVAEEngine:
             for i in range(1, len(Hd)):
                 self.dec.append(_Layer(f"dec{i}", f"decoder.HiddenL.L{i}.weight", None, None, Hd[i - 1], Hd[i],
                                        40 + i, f"dec{i}"))
-            if self.recon == "mse":
+            if self.recon in ("mse", "poisson"):      # scPoli's poisson head is also called recon_decoder (scpoli.py:607)
                 self.out_w, self.out_b = "decoder.recon_decoder.0.weight", "decoder.recon_decoder.0.bias"
             else:
                 self.out_w, self.out_b = "decoder.mean_decoder.0.weight", "decoder.mean_decoder.0.bias"
@@ -265,7 +267,7 @@ class CVAEEngine:
             if self.recon == "zinb":
                 _expect("decoder.dropout_decoder.weight", (G, Hd[-1]))
                 _expect("decoder.dropout_decoder.bias", (G,))
-        if self.recon != "mse" and self.C > 0:
+        if self.has_theta and self.C > 0:
             _expect("theta", (G, self.C))
         for k in fused_w:
             _expect(k, (self.Zx if "expand" in k else Z, H[-1]))
@@ -898,6 +900,12 @@ class CVAEEngine:
             _lib.check(L.sca_mse_rows(ws["logits"].data_ptr(), G, ws["x"].data_ptr(), G, B, G, rpb,
                                       ws["row_ll"].data_ptr(), gob, int(compute_grad), 1, None, None, st), "mse_rows")
             recon_sign = 1.0
+        elif self.recon == "poisson":
+            ip, ix, dv = self.csr
+            _lib.check(L.sca_poisson_rows(ws["logits"].data_ptr(), G, ip.data_ptr(), ix.data_ptr(), dv.data_ptr(),
+                                          ptr(row_ids), ws["sf"].data_ptr(), B, G, rpb, ws["row_ll"].data_ptr(),
+                                          int(compute_grad), st), "poisson_rows")
+            recon_sign = 1.0
         else:
             ip, ix, dv = self.csr
             _lib.check(L.sca_recon_rows(int(zinb), ws["logits"].data_ptr(), G, ws["pi"].data_ptr() if zinb else None,
@@ -924,7 +932,7 @@ class CVAEEngine:
         xp_c = self.arch == "expimap" and self.xp_wc
 
         def work(sa):
-            if self.recon != "mse":
+            if self.has_theta:
                 _lib.check(L.sca_theta_prep(P["theta"].data_ptr(), G, C, ws["tab_theta"].data_ptr(),
                                             ws["tab_lte"].data_ptr(), sa), "theta_prep")
                 if compute_grad:
@@ -963,12 +971,14 @@ class CVAEEngine:
 
         # ---- side work that depends only on the reconstruction kernel's outputs
         def recon_side(sa):
-            if self.recon != "mse" and T["theta"]:
+            if self.has_theta and T["theta"]:
                 # theta gradient: -1/B * sum_b theta dll/dtheta, transposed back to the [G][C] parameter layout
                 _lib.check(L.sca_transpose_scale(ws["dthetaT"].data_ptr(), max(C, 1), G, -1.0 / B,
                                                  Gd["theta"].data_ptr(), sa), "transpose_scale")
             if T[self.out_w]:
                 self._grad_gemm(1, 1, dl, G, h_last, Hd, G, Hd, B, sa, Gd[self.out_w])
+            if self.recon == "poisson" and T[self.out_b]:      # (the other likelihood kernels accumulate it themselves)
+                self._colsum(dl, B, G, None, 0, None, Gd[self.out_b].data_ptr(), sa)
             if self.recon == "zinb" and T["decoder.dropout_decoder.weight"]:
                 self._grad_gemm(1, 1, ws["pi"].data_ptr(), G, h_last, Hd, G, Hd, B, sa,
                                 Gd["decoder.dropout_decoder.weight"])
@@ -1175,7 +1185,7 @@ class CVAEEngine:
         def recon_side(sa):
             if T[self.out_w]:
                 self._grad_gemm(1, 1, dl, G, h_last, Hd, G, Hd, B, sa, Gd[self.out_w])
-            if self.recon != "mse" and T["theta"]:
+            if self.has_theta and T["theta"]:
                 _lib.check(L.sca_transpose_scale(ws["dthetaT"].data_ptr(), max(C, 1), G, -1.0 / B,
                                                  Gd["theta"].data_ptr(), sa), "transpose_scale")
         self._defer(recon_side, lane=1)         # own stream: starts right behind the likelihood kernel
@@ -1359,7 +1369,7 @@ class CVAEEngine:
         dl = ws["logits"].data_ptr()
 
         def side(sa):
-            if self.recon != "mse" and T["theta"]:
+            if self.has_theta and T["theta"]:
                 _lib.check(L.sca_transpose_scale(ws["dthetaT"].data_ptr(), max(C, 1), G, -1.0 / B,
                                                  Gd["theta"].data_ptr(), sa), "transpose_scale")
             if any(T[k] for (k, _, _) in self.xp_parts):

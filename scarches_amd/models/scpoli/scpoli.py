@@ -54,8 +54,8 @@ class scpoli(EngineBackedModule):
             self.new_prototypes = [n_old + i for i in range(self.n_cell_types - n_old)]
         self.dr_rate = dr_rate
         self.use_dr = self.dr_rate > 0
-        if recon_loss not in ("nb", "zinb", "mse"):
-            raise NotImplementedError(f"recon_loss={recon_loss!r} is not built in the HIP path (nb, zinb, mse are); "
+        if recon_loss not in ("nb", "zinb", "mse", "poisson"):
+            raise NotImplementedError(f"recon_loss={recon_loss!r} is not built in the HIP path (nb, zinb, mse, poisson are); "
                                       "the reference's 'nb_dist' and 'bernoulli' branches are broken upstream")
         if recon_loss in ["nb", "zinb"]:
             self.theta = torch.nn.Parameter(torch.randn(self.input_dim, self.n_conditions_combined))

@@ -81,6 +81,8 @@ class Decoder(nn.Module):
         print("\tOutput Layer in/out: ", sizes[-2], sizes[-1], "\n")
         if recon_loss == "mse":
             self.recon_decoder = nn.Sequential(nn.Linear(sizes[-2], sizes[-1]), nn.ReLU())
+        if recon_loss == "poisson":      # scPoli's copy of the decoder only (models/scpoli/scpoli.py:607-609)
+            self.recon_decoder = nn.Sequential(nn.Linear(sizes[-2], sizes[-1]), nn.Softmax(dim=-1))
         if recon_loss == "zinb":
             self.mean_decoder = nn.Sequential(nn.Linear(sizes[-2], sizes[-1]), nn.Softmax(dim=-1))
             self.dropout_decoder = nn.Linear(sizes[-2], sizes[-1])

@@ -10,7 +10,7 @@ from tests._util import GOLDEN, dense_from_case, golden_ref64, grads_close, load
 
 torch.set_num_threads(1)
 TOL = 1e-5
-SCPOLI_CASES = ["scpoli_nb_two_cov", "scpoli_nb_deep", "scpoli_mse_dec_only", "scpoli_zinb"]
+SCPOLI_CASES = ["scpoli_nb_two_cov", "scpoli_nb_deep", "scpoli_mse_dec_only", "scpoli_zinb", "scpoli_poisson"]
 
 
 def run(z, cfg, W, masks, P=None):
@@ -36,7 +36,7 @@ def test_scpoli_losses_and_grads(name):
             assert rel_err(aux["P"][k].detach().numpy(), z["w_after/" + k]) < 1e-6, k
 
 
-@pytest.mark.parametrize("name", ["scpoli_nb_two_cov", "scpoli_nb_deep", "scpoli_mse_dec_only"])
+@pytest.mark.parametrize("name", ["scpoli_nb_two_cov", "scpoli_nb_deep", "scpoli_mse_dec_only", "scpoli_poisson"])
 def test_scpoli_adam_two_groups(name):
     """Adam with the embeddings in their own weight_decay=0 group (trainers/scpoli/trainer.py:288-305)."""
     z, cfg, W, _, masks = load_case(name)
