@@ -359,6 +359,19 @@ class CVAEEngine:
         ev.record(torch.cuda.current_stream(self.device))
         self._hyper_ev[i] = ev
 
+    # `noise_off = True` replaces the reparameterisation noise by zeros wherever no eps is injected (z = mean): the
+    # reference samples also in eval mode (_base.py:391-407), so fixtures of its sampled outputs (classify,
+    # get_recon_loss, add_new_cell_type) are taken with the noise switched off on both sides
+    noise_off = False
+
+    def _eps_or_zero(self, eps, B):
+        if eps is not None or not self.noise_off:
+            return eps
+        z = getattr(self, "_zero_eps", None)
+        if z is None or z.shape[0] < B:
+            z = self._zero_eps = torch.zeros(max(B, 1024), self.Zt, dtype=torch.float32, device=self.device)
+        return z
+
     def bind_csr(self, indptr: torch.Tensor, indices: torch.Tensor, data: torch.Tensor):
         """CSR matrix resident in HBM: indptr int64 [N+1], indices int32 [nnz], data float32 [nnz]."""
         assert indptr.dtype == torch.int64 and indices.dtype == torch.int32 and data.dtype == torch.float32
@@ -791,6 +804,7 @@ class CVAEEngine:
         compute_grad, the gradients of recon + hyper[0]*kl + mmd in self.flat_g.  Nothing is synchronised."""
         L, P = self.lib, self.p
         self._ensure(B)
+        eps = self._eps_or_zero(eps, B)
         ws = self.ws
         st = torch.cuda.current_stream(self.device).cuda_stream
         G, C, Z = self.G, self.C, self.Zt
@@ -1748,6 +1762,7 @@ class CVAEEngine:
         """Eval-mode encoder pass: returns (z or mean [B,Z], mean, var) device tensors (views of the workspace)."""
         L, P = self.lib, self.p
         self._ensure(B)
+        eps = self._eps_or_zero(eps, B)
         ws = self.ws
         st = torch.cuda.current_stream(self.device).cuda_stream
         ptr = _lib.ptr

@@ -268,16 +268,15 @@ class scPoli(BaseMixin):
         eng = self.model.engine()
         dev = ds.to_device(eng.device)
         eng.bind_csr(dev["indptr"], dev["indices"], dev["data"])
-        was_training = self.model.training
-        self.model.eval()
+        # like the reference (scpoli_model.py:919-947) the model's current mode decides whether dropout is active;
+        # shot_surgery switches to eval() before it calls this
         total, n = 0.0, len(ds)
         for lo in range(0, n, batch_size):
             hi = min(n, lo + batch_size)
             rows = torch.arange(lo, hi, device=eng.device, dtype=torch.int64)
-            eng.forward_backward(rows, dev["cond"][lo:hi].contiguous(), hi - lo, train=False, compute_grad=False,
-                                 accumulate_logs=False, covs=dev["covs"][lo:hi].contiguous())
+            eng.forward_backward(rows, dev["cond"][lo:hi].contiguous(), hi - lo, train=self.model.training,
+                                 compute_grad=False, accumulate_logs=False, covs=dev["covs"][lo:hi].contiguous())
             total += float(eng.losses[0]) * (hi - lo)
-        self.model.train(was_training)
         return total / n
 
     # ------------------------------------------------------------------------------------------ persistence / surgery
