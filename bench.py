@@ -247,6 +247,17 @@ def main():
     dt = run(B, a.steps, a.warmup)
     value = B * world * a.steps / dt
     losses = eng.losses.tolist()
+    extra = {}
+    if world > 1:
+        # the same workload under the OTHER MMD semantics, so one line shows what the reference's global-minibatch MMD
+        # (all-gather of z, O(B_global^2) pair evaluations over the job) costs next to the per-rank estimator
+        other = "local" if a.dp_mmd == "exact" else "exact"
+        eng.set_dp(rank, world, exact_mmd=(other == "exact"))
+        dt_other = run(B, a.steps, a.warmup)
+        eng.set_dp(rank, world, exact_mmd=(a.dp_mmd == "exact"))
+        extra = {f"dp_mmd_{a.dp_mmd}_ms_per_step": dt / a.steps * 1e3,
+                 f"dp_mmd_{other}_ms_per_step": dt_other / a.steps * 1e3,
+                 f"dp_mmd_{other}_cells_per_s": B * world * a.steps / dt_other}
 
     out = {
         "metric": "train cells/sec (fwd+bwd+Adam) trVAE 2k-HVG", "value": value, "unit": "cells/s",
@@ -261,6 +272,8 @@ def main():
                           ("global minibatch (all-gather of z)" if a.dp_mmd == "exact" else "per-rank slice")},
         "final_losses": {"recon": losses[0], "kl": losses[1], "mmd": losses[2]},
     }
+    if extra:
+        out["extra"] = extra
 
     if rank == 0:
         eng._dp = None      # the replays below run on rank 0 only: no collective may be part of them

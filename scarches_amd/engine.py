@@ -37,7 +37,7 @@ class _Layer:
         self.bn = bn        # state-dict prefix of the BatchNorm1d after this Linear (use_bn), e.g. "encoder.FC.N0"
 
 
-_QUERIES = {"sca_gemm_kk_supported", "sca_gemm_kk_splitk_heuristic", "sca_mid_max_width", "sca_grad_tail_max_jobs", "sca_gemm_group_max_jobs", "sca_gemm_splitk_heuristic", "sca_mmd_num_slabs", "sca_mmd_num_partials", "sca_hsic_workspace_floats",
+_QUERIES = {"sca_gemm_kk_supported", "sca_gemm_kk_splitk_heuristic", "sca_mid_max_width", "sca_grad_tail_max_jobs", "sca_gemm_group_max_jobs", "sca_gemm_splitk_heuristic", "sca_mmd_num_slabs", "sca_mmd_num_partials", "sca_mmd_rows_num_slabs", "sca_mmd_rows_num_partials", "sca_hsic_workspace_floats",
             "sca_proto_workspace_bytes", "sca_abi_version", "sca_device_name"}
 
 
@@ -82,6 +82,7 @@ class CVAEEngine:
         self._ws_gen = 0
         self._plans = {}
         self._adam_after_tail = None    # (weight_decay, wd_overrides): train_step on one device queues Adam on the aux stream
+        self._dp_dry = False            # True while a warm-up / recording pass runs: data-parallel gathers stay local
         self._adam_done = False
         self._mid_max_split = None      # optional split-K cap of the two GEMMs whose slabs the fused kernels sum
         self.lib = _RecordingLib(_lib.load(), self)
@@ -1512,6 +1513,18 @@ class CVAEEngine:
         return b
 
     def _dp_gather(self, out, local):
+        if self._dp_dry:
+            # warm-up / plan-recording pass: NO collective (ranks record their plans at different steps - ragged last
+            # minibatches give them different local sizes - so a collective here would pair with nothing and hang the
+            # job); the rank's own rows stand in for the gathered minibatch, the pass's results are discarded
+            n = local.shape[0]
+            if out.dtype.is_floating_point:
+                out.zero_()
+            else:
+                out.fill_(-1)          # condition -1 = padding row, ignored by the kernels
+            r = self._dp["rank"]
+            out[r * n:(r + 1) * n].copy_(local)
+            return
         if self._dp["gather"] is not None:
             self._dp["gather"](out, local)
         else:
@@ -1613,17 +1626,17 @@ class CVAEEngine:
         dp_exact = world > 1 and self._dp_exact()
         if dp_exact:
             self._dp_n_global = int(n_global) if n_global is not None else B * world
-            # The step holds two all-gathers in its middle: it is launched eagerly.  (Every rank must issue the same
-            # collectives in the same order: a ragged last minibatch gives the ranks different local sizes - or none,
-            # dp_idle_step - so ranks would record plans at different steps, and recording runs the step twice.)
-            use_graph = False
+            # The step holds two all-gathers in its middle: they are host calls inside the recorded launch plan (not
+            # graph-capturable).  Every rank issues exactly two gathers + one all-reduce per step whatever the state
+            # of its plans: warm-up and recording passes gather nothing (_dp_dry), so ranks may record at different
+            # steps (ragged last minibatches give them different local sizes).
+            if use_graph is True:
+                use_graph = "plan"
         if use_graph is False:
             self.begin_step(alpha_kl, lr, eps, clip)
             self._step_and_adam(row_ids, cond, B, weight_decay, wd_overrides, world > 1)
             if world > 1:
-                from . import distributed as sdist
-                sdist.allreduce_mean_(self.flat_g, world, weight=grad_weight)
-                self.adam_step(weight_decay, wd_overrides)
+                self._allreduce_and_adam(world, grad_weight, weight_decay, wd_overrides)
             return self.losses
         def plan_key():
             return (B, use_graph is True, float(weight_decay), tuple(sorted((wd_overrides or {}).items())), world > 1,
@@ -1654,13 +1667,29 @@ class CVAEEngine:
         else:
             self._replay(g["fwd"])
         if world > 1:
-            from . import distributed as sdist
-            sdist.allreduce_mean_(self.flat_g, world, weight=grad_weight)
-            if use_graph is True:
-                g["adam"].replay()
-            else:
-                self._replay(g["adam"])
+            self._allreduce_and_adam(world, grad_weight, weight_decay, wd_overrides)
         return self.losses
+
+    def _allreduce_and_adam(self, world, grad_weight, weight_decay, wd_overrides):
+        """Data-parallel end of a step: ONE all-reduce of the flat gradient buffer and the replicated Adam update, both
+        queued on the aux stream - the stream the gradient tail just ran on - so the collective starts the moment the
+        last reduction is done (RCCL orders itself after the stream it is issued from) and Adam waits for nothing but
+        the collective; the main stream joins once, behind Adam."""
+        from . import distributed as sdist
+        main = torch.cuda.current_stream(self.device)
+        if not self.overlap:
+            sdist.allreduce_mean_(self.flat_g, world, weight=grad_weight)
+            self.adam_step(weight_decay, wd_overrides)
+            return
+        ev = self._next_event()
+        ev.record(main)
+        self.aux.wait_event(ev)
+        with torch.cuda.stream(self.aux):
+            sdist.allreduce_mean_(self.flat_g, world, weight=grad_weight)
+            self.adam_step(weight_decay, wd_overrides, stream=self.aux.cuda_stream)
+        ev2 = self._next_event()
+        ev2.record(self.aux)
+        main.wait_event(ev2)
 
     def _step_and_adam(self, rows, cond, B, weight_decay, wd_overrides, split):
         """forward + backward and - unless a gradient all-reduce sits between them (`split`) - Adam, queued right
@@ -1689,7 +1718,11 @@ class CVAEEngine:
         cond = torch.zeros(B, dtype=torch.int32, device=self.device)
         snap = (self.flat_p.clone(), self.flat_m.clone(), self.flat_v.clone(), self.accum.clone(),
                 {k: v.clone() for k, v in self.buffers.items()})
-        self._step_and_adam(rows, cond, B, weight_decay, wd_overrides, False)
+        self._dp_dry = True
+        try:
+            self._step_and_adam(rows, cond, B, weight_decay, wd_overrides, False)
+        finally:
+            self._dp_dry = False
         torch.cuda.synchronize(self.device)
         return rows, cond, snap
 
@@ -1704,16 +1737,13 @@ class CVAEEngine:
         rows, cond, snap = self._warm(B, weight_decay, wd_overrides)
         out = dict(rows=rows, cond=cond)
         self._rec = []
+        self._dp_dry = True            # the launches run while they are recorded; the replays gather for real
         try:
             self._step_and_adam(rows, cond, B, weight_decay, wd_overrides, split)
-            if split:
-                out["fwd"], self._rec = self._rec, []
-                self.adam_step(weight_decay, wd_overrides)
-                out["adam"] = self._rec
-            else:
-                out["fwd"] = self._rec
+            out["fwd"] = self._rec     # (split: Adam follows the gradient all-reduce, _allreduce_and_adam)
         finally:
             self._rec = None
+            self._dp_dry = False
         self._restore(snap)
         return out
 
@@ -1729,11 +1759,6 @@ class CVAEEngine:
         with torch.cuda.graph(gf):
             self._step_and_adam(rows, cond, B, weight_decay, wd_overrides, split)
         out["fwd"] = gf
-        if split:
-            ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
-                self.adam_step(weight_decay, wd_overrides)
-            out["adam"] = ga
         self._restore(snap)
         return out
 

@@ -111,6 +111,26 @@ def _worker(rank, port, out_dir):
         decisions.append((bool(cont), bool(lr)))
         if not cont:
             break
+    # ---- (4) epoch logs on ragged shards: every rank accumulates its minibatch means with weight n_local / n_global
+    # (hyper[6] of sca_finalize_losses, Trainer._set_log_weight); the all-reduced sums are the single-process epoch
+    # means over the GLOBAL minibatches (sizes 15, 15, 7 -> slices 8+7, 8+7, 4+3)
+    acc = torch.zeros(3, dtype=torch.float64)           # [sum w*recon, sum w*kl, sum w]
+    ref = torch.zeros(3, dtype=torch.float64)
+    xx = dense_from_case(z, cfg["G"])
+    for b0, nb in ((0, 15), (1, 15), (3, 7)):
+        sl = slice(b0, b0 + nb)
+        rg, _, _ = O.trvae_loss_and_grads(W, cfg, xx[sl], z["batch"][sl], torch.tensor(z["sizefactor"][sl]),
+                                          torch.tensor(z["eps"][sl]), alpha)
+        ref += torch.tensor([rg["recon"], rg["kl"], 1.0], dtype=torch.float64)
+        lo, hi = sdist.shard_range(nb, rank, WORLD)
+        rl, _, _ = O.trvae_loss_and_grads(W, cfg, xx[sl][lo:hi], z["batch"][sl][lo:hi],
+                                          torch.tensor(z["sizefactor"][sl][lo:hi]), torch.tensor(z["eps"][sl][lo:hi]),
+                                          alpha)
+        w_ = (hi - lo) / nb
+        acc += w_ * torch.tensor([rl["recon"], rl["kl"], 1.0], dtype=torch.float64)
+    sdist.allreduce_sum_(acc)
+    res["log_err"] = float(((acc[:2] / acc[2]) - (ref[:2] / ref[2])).abs().max() / (ref[:2] / ref[2]).abs().max())
+    res["log_count"] = float(acc[2])
     dist.all_gather_object(allres := [None] * WORLD, decisions)
     res["same_decisions"] = allres[0] == allres[1]
     res["stopped"] = not decisions[-1][0]
@@ -129,6 +149,7 @@ def test_dp_two_ranks_gloo(tmp_path):
         assert res["grad_err_equal"] < 1e-5, res
         assert res["grad_err_mmd"] < 1e-5 and res["mmd_err"] < 1e-5, res
         assert res["same_decisions"] and res["stopped"]
+        assert res["log_err"] < 1e-6 and abs(res["log_count"] - 3.0) < 1e-12, res
 
 
 def test_shard_range_partitions():

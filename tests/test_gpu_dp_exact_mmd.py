@@ -111,9 +111,10 @@ def test_exact_dp_mmd_matches_single_device(data, mmd_on, boundary):
     assert_grads_close(acc, gf, rtol=2e-4)
 
 
-def test_exact_dp_train_step_is_eager_with_one_gather_pair_per_step(data):
-    """train_step under exact DP MMD launches eagerly whatever launch mode is asked for (every rank issues exactly one
-    gather pair per step, ragged minibatch or not) and all modes give the same trajectory."""
+def test_exact_dp_train_step_issues_one_gather_pair_per_step_in_every_launch_mode(data):
+    """train_step under exact DP MMD: eager launches and the recorded launch plan (a requested HIP graph becomes a plan:
+    the gathers are host calls) issue exactly one gather pair per step - the plan's warm-up and recording passes gather
+    nothing, so ranks may record at different steps - and all modes give the same trajectory."""
     import torch.distributed as dist
     if not dist.is_initialized():
         import os

@@ -61,3 +61,39 @@ def test_dp_step_modes_agree(group, B):
         # three optimiser steps: float-atomic ordering noise (theta / bias / MMD column sums) compounds, rel 1e-4
         assert np.all(np.abs(out[0][:3] - ref[0][:3]) <= 1e-4 * np.abs(ref[0][:3])), (mode, out[0], ref[0])
         assert float((out[1] - ref[1]).abs().max()) <= 1e-4 * float(ref[1].abs().max()), mode
+
+
+def test_epoch_log_weights_of_ragged_slices_add_up():
+    """Epoch logs under data parallelism: a rank accumulates its minibatch means with weight n_local / n_global
+    (hyper[6] of sca_finalize_losses, Trainer._set_log_weight).  Two 'ranks' on one GPU over ragged slices of three
+    global minibatches: the summed accumulators equal those of the single-device run over the whole minibatches."""
+    from bench import build_trvae_params
+    from scarches_amd import distributed as sdist
+    from scarches_amd.engine import CVAEEngine
+    from scarches_amd.synth import make_synthetic_csr
+    dev = torch.device("cuda", 0)
+    Gs, Cs, Hs, Zs = 300, 4, [32, 16], 6
+    indptr, indices, vals, cond_all, _ = make_synthetic_csr(3000, Gs, Cs, dev, seed=8)
+    spec = dict(G=Gs, C=Cs, H=Hs, Z=Zs, recon="nb", use_bn=False, use_ln=True, use_mmd=False, dr_rate=0.0, seed=1)
+
+    def engine():
+        e = CVAEEngine(spec, build_trvae_params(Gs, Cs, Hs, Zs), dev)
+        e.bind_csr(indptr, indices, vals)
+        e.set_hyper(alpha_kl=0.5)
+        return e
+    gen = torch.Generator(device=dev).manual_seed(3)
+    batches = [torch.randperm(3000, generator=gen, device=dev)[:n] for n in (101, 101, 37)]
+    eps = [torch.randn(b.numel(), Zs, device=dev, generator=gen) for b in batches]
+    full, ranks = engine(), [engine(), engine()]
+    for b, e_ in zip(batches, eps):
+        full.forward_backward(b, cond_all[b].to(torch.int32), b.numel(), compute_grad=False, eps=e_)
+        for r, eng in enumerate(ranks):
+            lo, hi = sdist.shard_range(b.numel(), r, 2)
+            eng.set_hyper(log_weight=(hi - lo) / b.numel())
+            eng.forward_backward(b[lo:hi].contiguous(), cond_all[b[lo:hi]].to(torch.int32), hi - lo,
+                                 compute_grad=False, eps=e_[lo:hi].contiguous())
+    torch.cuda.synchronize()
+    ref = full.accum.cpu().numpy()
+    got = ranks[0].accum.cpu().numpy() + ranks[1].accum.cpu().numpy()
+    assert abs(ref[4] - 3.0) < 1e-12 and abs(got[4] - 3.0) < 1e-6
+    assert np.all(np.abs(got[:2] - ref[:2]) <= 1e-5 * np.abs(ref[:2])), (got, ref)
