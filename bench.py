@@ -86,41 +86,80 @@ def epoch_batches(cond_all, n_batches, B, gen):
     return torch.gather(ids, 1, order).contiguous(), torch.gather(c, 1, order).contiguous()
 
 
-def cpu_baseline(P, spec, csr_host, cond_host, B, budget_s=12.0):
+# The REAL reference (theislab/scarches trVAE, imported from /root/reference) timed in the BUILD container by
+# scripts/ref_cpu_probe.py (8 vCPU, torch 2.10 CPU, cfg2 shape G=2000 / C=20 / [128,128], fwd + bwd + Adam on an already
+# collated dense minibatch, best thread count per batch size).  The reference cannot travel to the GPU box, so this is
+# a stated constant with its provenance, not a measurement of this run.
+REFERENCE_IN_CONTAINER = {
+    "what": "real scarches trVAE (CPU, fwd+bwd+Adam, dense minibatch already collated), build container, 8 vCPU",
+    "cells_per_s": {"B=128": {"threads": 1, "value": 463.0}, "B=1024": {"threads": 8, "value": 1558.0}},
+    "script": "scripts/ref_cpu_probe.py",
+}
+
+
+def cpu_baseline(P, spec, csr_host, cond_host, budget_s=12.0):
     """The oracle (a torch-CPU restatement of the reference, oracle/cvae_oracle.py) timed on this box's host cores:
-    fwd + autograd bwd + Adam on minibatches of the same workload.  Checker code used as a *baseline only*."""
+    CSR row slice + fwd + autograd bwd + Adam on minibatches of the same workload, as a small table over
+    threads in {1, cores/2, cores} x B in {128 (the reference's default), 1024} inside one time budget.  `value` is
+    the best cell of the table.  Checker code used as a *baseline only*."""
     import numpy as np
+    import scipy.sparse as sp
     from oracle import cvae_oracle as O
-    threads = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
+    cores = min(16, os.cpu_count() or 1)
     indptr, indices, data = csr_host
     n = len(indptr) - 1
-    rng = np.random.default_rng(0)
-    cfg = dict(spec)
-    Pn = {k: v.clone() for k, v in P.items()}
-    M = {k: torch.zeros_like(v) for k, v in Pn.items()}
-    V = {k: torch.zeros_like(v) for k, v in Pn.items()}
-    done, t0, t = 0, time.time(), 0
-    import scipy.sparse as sp
     mat = sp.csr_matrix((data, indices, indptr), shape=(n, spec["G"]))
-    while True:
-        rows = np.sort(rng.integers(0, n, size=B))
-        x = torch.tensor(mat[rows].toarray())
-        cond = cond_host[rows]
-        eps = torch.randn(B, spec["Z"])
-        masks = None
-        _, grads, _ = O.trvae_loss_and_grads({k: v.numpy() for k, v in Pn.items()}, cfg, x, cond, x.sum(1), eps, 0.5,
-                                             masks)
-        t += 1
-        for k in Pn:
-            O.adam_step(Pn[k], grads[k], M[k], V[k], t)
-        done += B
-        if time.time() - t0 > budget_s:
-            break
-    dt = time.time() - t0
-    return dict(value=done / dt, unit="cells/s", cores=threads, kind="port",
-                sample=f"{t} steps of B={B} (CSR row slice + fwd + autograd bwd + Adam, dropout off), "
-                       f"{dt:.1f} s on {threads} torch threads")
+    cfg = dict(spec)
+    grid = [(t, B) for B in (128, 1024) for t in sorted({1, max(1, cores // 2), cores})]
+    per = budget_s / len(grid)
+    table, best = [], None
+    for threads, B in grid:
+        torch.set_num_threads(threads)
+        rng = np.random.default_rng(0)
+        Pn = {k: v.clone() for k, v in P.items()}
+        M = {k: torch.zeros_like(v) for k, v in Pn.items()}
+        V = {k: torch.zeros_like(v) for k, v in Pn.items()}
+        done, t, t0 = 0, 0, None
+        while True:
+            rows = np.sort(rng.integers(0, n, size=B))
+            x = torch.tensor(mat[rows].toarray())
+            eps = torch.randn(B, spec["Z"])
+            _, grads, _ = O.trvae_loss_and_grads({k: v.numpy() for k, v in Pn.items()}, cfg, x, cond_host[rows],
+                                                 x.sum(1), eps, 0.5, None)
+            t += 1
+            for k in Pn:
+                O.adam_step(Pn[k], grads[k], M[k], V[k], t)
+            if t0 is None:          # first step = warm-up (thread pool, allocator)
+                t0 = time.time()
+                continue
+            done += B
+            if time.time() - t0 > per:
+                break
+        rate = done / (time.time() - t0)
+        table.append({"threads": threads, "B": B, "cells_per_s": rate, "steps": t - 1})
+        if best is None or rate > best[0]:
+            best = (rate, threads, B)
+    return dict(value=best[0], unit="cells/s", cores=best[1], kind="port",
+                sample=f"best of {len(grid)} cells (threads x B) of ~{per:.1f} s each: B={best[2]} on {best[1]} torch "
+                       f"threads (CSR row slice + fwd + autograd bwd + Adam, dropout off)",
+                table=table, reference_in_container=REFERENCE_IN_CONTAINER)
+
+
+def step_roofline(G, H, Z, n_params, nnz_per_cell, B, cells_per_s_per_gpu):
+    """Whole-step roofline of SURVEY.md 8(d): GEMM flops per cell (fwd + dW + dX) against the fp32 MFMA peak and the
+    ideal-fusion HBM bytes per cell (logits round trip kept, Adam traffic amortised over the minibatch) against the
+    HBM peak; the step's roofline is the smaller of the two rates."""
+    Hd = list(reversed(H))
+    F = 2.0 * (G * H[0] + sum(a * b for a, b in zip(H[:-1], H[1:])) + 2 * H[-1] * Z) \
+        + 2.0 * (Z * Hd[0] + sum(a * b for a, b in zip(Hd[:-1], Hd[1:])) + Hd[-1] * G)
+    flop = 3.0 * F - 2.0 * G * H[0]
+    byt = 32.0 * G + 8.0 * nnz_per_cell + 28.0 * n_params / B
+    r_mfma, r_hbm = 157.3e12 / flop, 8.0e12 / byt
+    roof = min(r_mfma, r_hbm)
+    return {"flop_per_cell": flop, "bytes_per_cell": byt, "bound": "mfma" if r_mfma <= r_hbm else "hbm",
+            "mfma_cells_per_s": r_mfma, "hbm_cells_per_s": r_hbm, "roofline_cells_per_s": roof,
+            "achieved_cells_per_s": cells_per_s_per_gpu, "frac": cells_per_s_per_gpu / roof,
+            "achieved_tflops": cells_per_s_per_gpu * flop / 1e12, "achieved_gb_per_s": cells_per_s_per_gpu * byt / 1e9}
 
 
 def hbm_kernel_rates(eng, B, G, nnz_per_cell, launch, reps=20):
@@ -322,6 +361,8 @@ def main():
                            "launches_per_step": len(calls), "flop_per_step": flops,
                            "avg_launch_us": t_gemm / len(calls) * 1e6,
                            "gemm_share_of_step": t_gemm / (dt / a.steps)}
+        out["roofline"]["step"] = step_roofline(G, H, Z, sum(v.numel() for v in P.values()), data.numel() / n_local,
+                                                B, value / world)
         out["hbm_kernels"] = hbm_kernel_rates(eng, B, G, data.numel() / n_local, a.launch)
         if not a.no_sweep and world == 1:
             sweep = {}
@@ -333,7 +374,7 @@ def main():
             out["cells_per_s_by_batch"] = sweep
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(P, spec, (indptr.cpu().numpy(), indices.cpu().numpy(),
-                                                         data.cpu().numpy()), cond_all.cpu().numpy(), min(B, 1024))
+                                                         data.cpu().numpy()), cond_all.cpu().numpy())
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
