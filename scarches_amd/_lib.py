@@ -95,6 +95,15 @@ SIGNATURES = {
     "sca_begin_step_batch": [P, P, F, F, F, F, F, F, P, P, P, P, I, P],
     "sca_fill_zero": [P, LL, P],
     "sca_masked_copy": [P, I, P, I, P, I, I, I, P],
+    "sca_masked_max_cols": [],
+    "sca_masked_fwd_tiles_per_wg": [I, I],
+    "sca_masked_dx_slabs": [I, I],
+    "sca_masked_dw_slabs": [I, I],
+    "sca_masked_pack": [P, I, P, P, I, I, I, I, P, P],
+    "sca_masked_unpack": [P, I, LL, P, P, I, I, I, I, P, I, P],
+    "sca_masked_fwd": [P, I, P, P, P, I, I, I, I, I, P, I, P],
+    "sca_masked_dx": [P, I, P, P, P, I, I, I, I, I, P, LL, P],
+    "sca_masked_dw": [P, I, P, I, P, P, I, I, I, I, I, P, LL, P],
     "sca_prox_l1": [P, LL, F, P, P],
     "sca_prox_group_lasso": [P, I, I, F, P, P],
     "sca_hsic_workspace_floats": [I],

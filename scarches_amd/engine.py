@@ -37,8 +37,11 @@ class _Layer:
         self.bn = bn        # state-dict prefix of the BatchNorm1d after this Linear (use_bn), e.g. "encoder.FC.N0"
 
 
-_QUERIES = {"sca_gemm_kk_supported", "sca_gemm_kk_splitk_heuristic", "sca_mid_max_width", "sca_grad_tail_max_jobs", "sca_gemm_group_max_jobs", "sca_gemm_splitk_heuristic", "sca_mmd_num_slabs", "sca_mmd_num_partials", "sca_mmd_rows_num_slabs", "sca_mmd_rows_num_partials", "sca_hsic_workspace_floats",
-            "sca_proto_workspace_bytes", "sca_abi_version", "sca_device_name"}
+_QUERIES = {"sca_gemm_kk_supported", "sca_gemm_kk_splitk_heuristic", "sca_mid_max_width", "sca_grad_tail_max_jobs",
+            "sca_gemm_group_max_jobs", "sca_gemm_splitk_heuristic", "sca_mmd_num_slabs", "sca_mmd_num_partials",
+            "sca_mmd_rows_num_slabs", "sca_mmd_rows_num_partials", "sca_hsic_workspace_floats",
+            "sca_proto_workspace_bytes", "sca_abi_version", "sca_device_name", "sca_masked_dw_slabs",
+            "sca_masked_dx_slabs", "sca_masked_max_cols", "sca_masked_fwd_tiles_per_wg"}
 
 
 class _RecordingLib:
@@ -222,6 +225,7 @@ class CVAEEngine:
                 assert md is None or tuple(md.shape) == (G, w), "mask must be [G, n_terms] (MaskedLinear.mask layout)"
             self.xp_wc = "decoder.L0.cond_L.weight" if has_c else None
             self.out_w = self.out_b = None
+            self.masked = self._masked_meta()
         else:
             self.dec.append(_Layer("dec0", "decoder.FirstL.L0.expr_L.weight", None,
                                    "decoder.FirstL.L0.cond_L.weight" if has_c_dec else None, Z, Hd[0], 40, "dec0"))
@@ -379,6 +383,36 @@ class CVAEEngine:
         assert indptr.device == self.device and indices.device == self.device and data.device == self.device
         self.csr = (indptr.contiguous(), indices.contiguous(), data.contiguous())
 
+    def _masked_meta(self):
+        """Tile-skipping plan of the masked decoder (csrc/masked_gemm.hip): genes in tiles of 32, per tile the sorted
+        gene-program columns that are not fully masked for its genes, padded to an even count with a pointer at the
+        zero column Zt.  Built once from the binary pattern of the masks (MaskedLinear.mask never changes after
+        construction, modules.py:9-25); None = use the dense GEMMs (soft-mask / unmasked models, a plan that would
+        skip too little, or more columns than the kernels hold)."""
+        if os.environ.get("SCA_MASKED_GEMM", "1") == "0" or self.xp_masks[0] is None:
+            return None
+        G, Zt = self.G, self.Zt
+        pat = np.concatenate([np.ones((G, w), bool) if md is None else (md.cpu().numpy() != 0)
+                              for (_, w, _), md in zip(self.xp_parts, self.xp_masks)], axis=1)
+        NT = (G + 31) // 32
+        pad = np.zeros((NT * 32, Zt), bool)
+        pad[:G] = pat
+        active = pad.reshape(NT, 32, Zt).any(1)                    # [NT][Zt]
+        k = active.sum(1)
+        k_even = (k + 1) & ~1
+        Kmax = max(int(k_even.max()), 2)
+        skipped = 1.0 - float(k_even.sum()) / (NT * Zt)
+        min_skip = float(os.environ.get("SCA_MASKED_MIN_SKIP", 0.3))
+        if Kmax > self.lib.sca_masked_max_cols() or 128 * ((Zt + 1) | 1) * 4 > 158 * 1024 or skipped < min_skip:
+            return None
+        cols = np.full((NT, Kmax), Zt, np.int32)
+        for t in range(NT):
+            c = np.nonzero(active[t])[0]
+            cols[t, :len(c)] = c
+        dev = self.device
+        return dict(NT=NT, Kmax=Kmax, skipped=skipped, tile_k=torch.tensor(k_even.astype(np.int32), device=dev),
+                    tile_cols=torch.tensor(cols, device=dev), n=NT * Kmax * 32)
+
     def set_trainable(self, names):
         names = set(names)
         for k in self.names:
@@ -447,6 +481,14 @@ class CVAEEngine:
             ws["Weff"] = torch.empty(G, Z, dtype=f32, device=dev)      # packed [expr*mask | ext_m*mask | ext]
             ws["dWeff"] = torch.empty(G, Z, dtype=f32, device=dev)
             ws["coffT"] = torch.empty(C, G, dtype=f32, device=dev)     # decoder cond_L.weight transposed
+            if self.masked is not None:
+                mk = self.masked
+                bs = list(range(16, B, 16)) + [B]
+                ws["mk_Wc"] = torch.empty(mk["n"], dtype=f32, device=dev)
+                ws["mk_dWc"] = torch.empty(max(L.sca_masked_dw_slabs(b, mk["NT"]) for b in bs) * mk["n"], dtype=f32,
+                                           device=dev)
+                ws["mk_dz"] = torch.empty(max(L.sca_masked_dx_slabs(b, mk["NT"]) * b for b in bs) * Z, dtype=f32,
+                                          device=dev)
             if self.use_hsic:
                 ws["hsic_work"] = torch.empty(L.sca_hsic_workspace_floats(B), dtype=f32, device=dev)
                 ws["hsic_dz"] = torch.empty(B, Z, dtype=f32, device=dev)
@@ -1345,8 +1387,17 @@ class CVAEEngine:
             self._n_part = 1
         self._expimap_pack(st)
         coff = ws["coffT"].data_ptr() if self.xp_wc else None
-        self._gemm(0, 0, ws["z"].data_ptr(), Zt, ws["Weff"].data_ptr(), Zt, B, G, Zt, st,
-                   out=ws["logits"].data_ptr(), ldc=G, force_s1=True)
+        mk = self.masked
+        if mk is not None:
+            # tile-skipping masked decoder: compact weights of this step, then K_t (not Zt) k-steps per gene tile
+            mk_meta = (mk["tile_k"].data_ptr(), mk["tile_cols"].data_ptr(), mk["NT"], mk["Kmax"])
+            _lib.check(L.sca_masked_pack(ws["Weff"].data_ptr(), Zt, *mk_meta, G, Zt, ws["mk_Wc"].data_ptr(), st),
+                       "masked_pack")
+            _lib.check(L.sca_masked_fwd(ws["z"].data_ptr(), Zt, ws["mk_Wc"].data_ptr(), *mk_meta, B, G, Zt,
+                                        ws["logits"].data_ptr(), G, st), "masked_fwd")
+        else:
+            self._gemm(0, 0, ws["z"].data_ptr(), Zt, ws["Weff"].data_ptr(), Zt, B, G, Zt, st,
+                       out=ws["logits"].data_ptr(), ldc=G, force_s1=True)
         ev_side = self._flush()
         lenc = self.lenc if self.lenc_active else None
         sf_p = ws["sf"].data_ptr()
@@ -1388,7 +1439,15 @@ class CVAEEngine:
                 _lib.check(L.sca_transpose_scale(ws["dthetaT"].data_ptr(), max(C, 1), G, -1.0 / B,
                                                  Gd["theta"].data_ptr(), sa), "transpose_scale")
             if any(T[k] for (k, _, _) in self.xp_parts):
-                self._gemm_to(1, 1, dl, G, ws["z"].data_ptr(), Zt, G, Zt, B, sa, ws["dWeff"], slab_key=AUX)
+                if mk is not None:
+                    S_w = L.sca_masked_dw_slabs(B, mk["NT"])
+                    _lib.check(L.sca_masked_dw(ws["z"].data_ptr(), Zt, dl, G, *mk_meta, B, G, Zt,
+                                               ws["mk_dWc"].data_ptr(), mk["n"], sa), "masked_dw")
+                    self._zero(ws["dWeff"], sa)
+                    _lib.check(L.sca_masked_unpack(ws["mk_dWc"].data_ptr(), S_w, mk["n"], *mk_meta, G, Zt,
+                                                   ws["dWeff"].data_ptr(), Zt, sa), "masked_unpack_tiles")
+                else:
+                    self._gemm_to(1, 1, dl, G, ws["z"].data_ptr(), Zt, G, Zt, B, sa, ws["dWeff"], slab_key=AUX)
                 col = 0
                 for (k, w, _), md in zip(self.xp_parts, self.xp_masks):
                     if T[k]:
@@ -1400,7 +1459,11 @@ class CVAEEngine:
         self._defer(side)
         if lenc is not None:
             self._lenc_backward(B, cond_p, st)
-        sp, S, stride = self._gemm(0, 1, dl, G, ws["Weff"].data_ptr(), Zt, B, Zt, G, st)
+        if mk is not None:
+            sp, S, stride = ws["mk_dz"].data_ptr(), L.sca_masked_dx_slabs(B, mk["NT"]), B * Zt
+            _lib.check(L.sca_masked_dx(dl, G, ws["mk_Wc"].data_ptr(), *mk_meta, B, G, Zt, sp, stride, st), "masked_dx")
+        else:
+            sp, S, stride = self._gemm(0, 1, dl, G, ws["Weff"].data_ptr(), Zt, B, Zt, G, st)
         if self.use_hsic:
             self._wait(ev_side)
         self._backward_latent_encoder(B, cond_p, self._p_drop_cur, self._masks_cur, st, sp, S, stride,

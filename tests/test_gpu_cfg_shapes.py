@@ -149,6 +149,7 @@ def gene_program_mask(G, L, seed):
 @pytest.mark.parametrize("shape", [
     pytest.param(dict(G=5000, L=280, H=[256, 256, 256], C=4, B=256, soft=False), id="cfg3-G5000-L280-hard-B256"),
     pytest.param(dict(G=5000, L=280, H=[256, 256, 256], C=4, B=512, soft=True), id="cfg3-G5000-L280-soft-B512"),
+    pytest.param(dict(G=5000, L=280, H=[256, 256, 256], C=4, B=1000, soft=False), id="cfg3-G5000-L280-hard-B1000"),
 ])
 def test_expimap_step_at_config_shape(shape):
     from oracle import expimap_oracle as XO
@@ -177,6 +178,10 @@ def test_expimap_step_at_config_shape(shape):
     spec = dict(arch="expimap", G=G, C=C, H=H, Z=L, recon="nb", use_bn=False, use_ln=True, dr_rate=0.0, n_ext=0,
                 n_ext_m=0, mask=None if soft else torch.tensor(M.T.copy()), ext_mask=None, use_hsic=False)
     eng = CVAEEngine(spec, P, "cuda:0")
+    # Reactome-like hard masks go through the tile-skipping decoder kernels, soft masks through the dense GEMMs
+    assert (eng.masked is None) == soft
+    if not soft:
+        assert eng.masked["skipped"] > 0.5, eng.masked["skipped"]
     eng.bind_csr(*d["csr"])
     eps = torch.randn(B, L, generator=torch.Generator().manual_seed(3))
     alpha = 0.5
