@@ -279,16 +279,20 @@ int sca_hsic_fwd_bwd(const float* z, int ld, int B, int D, const uint8_t* side, 
 /* Tile-skipping masked decoder (csrc/masked_gemm.hip): the three products of MaskedLinear (modules.py:9-25) /
  * MaskedCondLayers.forward (modules.py:62-85) and of their autograd, issued only over the (32 genes x 2 programs)
  * sub-tiles of W o M that are not fully masked.  Plan, built once by the caller from the mask's nonzero pattern:
- * NT = ceil(G/32) gene tiles; tile_k[NT] = number of active columns of a tile, rounded up to even, <= Kmax (even,
- * <= sca_masked_max_cols()); tile_cols[NT][Kmax] = their sorted indices, padded with Zt (a column of zeros).
- *   sca_masked_pack   Wc[t][j][n] = Weff[32t+n][tile_cols[t][j]]  (Weff [G][ldw] = weight * mask, dense; Wc [NT][Kmax][32])
+ * NT = ceil(G/32) gene tiles; tile_k[NT] = number of active columns of a tile, rounded up to even, <= Kmax (a multiple
+ * of 8, <= sca_masked_max_cols()); tile_cols[NT][Kmax] = their sorted indices, padded with Zt (a column of zeros).
+ *   sca_masked_pack   Wc[t][j][n] = Weff[32t+n][tile_cols[t][j]]  (Weff [G][ldw] = weight * mask, dense).  Wc holds
+ *                     2 * NT*Kmax*32 floats: that array, then the same values in the forward kernel's fragment order;
+ *                     16-byte aligned
  *   sca_masked_fwd    out[b][g] = sum_j z[b][tile_cols[t][j]] * Wc[t][j][g - 32t]            (out [B][ldo], z [B][ldz])
  *   sca_masked_dx     dz slabs [S][B][Zt], S = sca_masked_dx_slabs(B, NT), summed by the consumer: dz = dl @ Weff
  *   sca_masked_dw     dWc slabs [S][NT][Kmax][32], S = sca_masked_dw_slabs(B, NT): dWc[t][j][n] = sum_b z[b][col j] dl[b][32t+n]
  *   sca_masked_unpack dWeff[32t+n][tile_cols[t][j]] = sum_s dWc[s][t][j][n]  (dWeff pre-zeroed by the caller; the entries
  *                     of masked-out weights inside an active column are removed by the mask multiply of sca_masked_copy)
- * Return -2 when Zt or Kmax exceed what the kernels stage in LDS / registers (the caller uses sca_gemm_f32 then). */
+ * Return -2 when Kmax > sca_masked_max_cols() or Zt > sca_masked_max_width(), the limits of what the kernels keep in
+ * registers / LDS (the caller uses sca_gemm_f32 then). */
 int sca_masked_max_cols(void);
+int sca_masked_max_width(void);
 int sca_masked_fwd_tiles_per_wg(int B, int NT);
 int sca_masked_dx_slabs(int B, int NT);
 int sca_masked_dw_slabs(int B, int NT);

@@ -96,6 +96,7 @@ SIGNATURES = {
     "sca_fill_zero": [P, LL, P],
     "sca_masked_copy": [P, I, P, I, P, I, I, I, P],
     "sca_masked_max_cols": [],
+    "sca_masked_max_width": [],
     "sca_masked_fwd_tiles_per_wg": [I, I],
     "sca_masked_dx_slabs": [I, I],
     "sca_masked_dw_slabs": [I, I],

@@ -41,7 +41,8 @@ _QUERIES = {"sca_gemm_kk_supported", "sca_gemm_kk_splitk_heuristic", "sca_mid_ma
             "sca_gemm_group_max_jobs", "sca_gemm_splitk_heuristic", "sca_mmd_num_slabs", "sca_mmd_num_partials",
             "sca_mmd_rows_num_slabs", "sca_mmd_rows_num_partials", "sca_hsic_workspace_floats",
             "sca_proto_workspace_bytes", "sca_abi_version", "sca_device_name", "sca_masked_dw_slabs",
-            "sca_masked_dx_slabs", "sca_masked_max_cols", "sca_masked_fwd_tiles_per_wg"}
+            "sca_masked_dx_slabs", "sca_masked_max_cols", "sca_masked_max_width",
+            "sca_masked_fwd_tiles_per_wg"}
 
 
 class _RecordingLib:
@@ -385,8 +386,8 @@ class CVAEEngine:
 
     def _masked_meta(self):
         """Tile-skipping plan of the masked decoder (csrc/masked_gemm.hip): genes in tiles of 32, per tile the sorted
-        gene-program columns that are not fully masked for its genes, padded to an even count with a pointer at the
-        zero column Zt.  Built once from the binary pattern of the masks (MaskedLinear.mask never changes after
+        gene-program columns that are not fully masked for its genes, padded to an even count (row length Kmax: a
+        multiple of 8) with pointers at the zero column Zt.  Built once from the binary pattern of the masks (MaskedLinear.mask never changes after
         construction, modules.py:9-25); None = use the dense GEMMs (soft-mask / unmasked models, a plan that would
         skip too little, or more columns than the kernels hold)."""
         if os.environ.get("SCA_MASKED_GEMM", "1") == "0" or self.xp_masks[0] is None:
@@ -400,10 +401,10 @@ class CVAEEngine:
         active = pad.reshape(NT, 32, Zt).any(1)                    # [NT][Zt]
         k = active.sum(1)
         k_even = (k + 1) & ~1
-        Kmax = max(int(k_even.max()), 2)
+        Kmax = max((int(k_even.max()) + 7) & ~7, 8)
         skipped = 1.0 - float(k_even.sum()) / (NT * Zt)
         min_skip = float(os.environ.get("SCA_MASKED_MIN_SKIP", 0.3))
-        if Kmax > self.lib.sca_masked_max_cols() or 128 * ((Zt + 1) | 1) * 4 > 158 * 1024 or skipped < min_skip:
+        if Kmax > self.lib.sca_masked_max_cols() or Zt > self.lib.sca_masked_max_width() or skipped < min_skip:
             return None
         cols = np.full((NT, Kmax), Zt, np.int32)
         for t in range(NT):
@@ -484,7 +485,7 @@ class CVAEEngine:
             if self.masked is not None:
                 mk = self.masked
                 bs = list(range(16, B, 16)) + [B]
-                ws["mk_Wc"] = torch.empty(mk["n"], dtype=f32, device=dev)
+                ws["mk_Wc"] = torch.empty(2 * mk["n"], dtype=f32, device=dev)      # dX layout + forward layout
                 ws["mk_dWc"] = torch.empty(max(L.sca_masked_dw_slabs(b, mk["NT"]) for b in bs) * mk["n"], dtype=f32,
                                            device=dev)
                 ws["mk_dz"] = torch.empty(max(L.sca_masked_dx_slabs(b, mk["NT"]) * b for b in bs) * Z, dtype=f32,

@@ -70,6 +70,11 @@ def main():
         desc = f"scPoli {n} x {G}, hidden [64], E=10, Z=10, 200 conditions, 30 cell types (last epoch with prototypes)"
     dt = timed(make, train)
     n_train = int(0.9 * n)
+    if which == "expimap":
+        mk = make().model.engine().masked
+        desc += (", decoder: dense GEMMs" if mk is None else
+                 f", decoder: tile-skipping (Kmax {mk['Kmax']} of {L} programs per 32-gene tile, "
+                 f"{100 * mk['skipped']:.1f} % of the k-steps skipped)")
     print(f"{desc}: batch {B}: {dt:.3f} s / epoch (train {n_train} + validation {n - n_train} cells) = "
           f"{n / dt / 1e6:.2f} M cells/s through the public API", flush=True)
 

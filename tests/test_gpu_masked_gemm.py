@@ -24,7 +24,7 @@ def plan(pat):
     pad[:G] = pat
     active = pad.reshape(NT, 32, Zt).any(1)
     k = (active.sum(1) + 1) & ~1
-    Kmax = max(int(k.max()), 2)
+    Kmax = max((int(k.max()) + 7) & ~7, 8)
     cols = np.full((NT, Kmax), Zt, np.int32)
     for t in range(NT):
         c = np.nonzero(active[t])[0]
@@ -52,7 +52,7 @@ def test_masked_products_match_dense_fp64(B, G, Zt, density):
     meta = (tk.data_ptr(), tc.data_ptr(), NT, Kmax)
     st = torch.cuda.current_stream().cuda_stream
     n = NT * Kmax * 32
-    Wc = torch.full((n,), float("nan"), device="cuda")
+    Wc = torch.full((2 * n,), float("nan"), device="cuda")
     _lib.check(L.sca_masked_pack(Weff.data_ptr(), Zt, *meta, G, Zt, Wc.data_ptr(), st), "pack")
     # forward
     out = torch.full((B, G), float("nan"), device="cuda")
@@ -88,7 +88,7 @@ def test_unsupported_plans_are_refused():
     x = torch.zeros(8, device="cuda")
     assert Kmax > L.sca_masked_max_cols()
     assert L.sca_masked_pack(x.data_ptr(), Zt, tk.data_ptr(), tc.data_ptr(), NT, Kmax, G, Zt, x.data_ptr(), None) == -2
-    assert L.sca_masked_fwd(x.data_ptr(), Zt, x.data_ptr(), tk.data_ptr(), tc.data_ptr(), NT + 1, 2, 8, G, Zt,
+    assert L.sca_masked_fwd(x.data_ptr(), Zt, x.data_ptr(), tk.data_ptr(), tc.data_ptr(), NT + 1, 8, 8, G, Zt,
                             x.data_ptr(), G, None) == -1
 
 
