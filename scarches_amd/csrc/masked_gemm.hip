@@ -112,6 +112,26 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ src, int ld
     }
 }
 
+// The active-column counts of a workgroup's tile range, fetched ONCE into registers (lane l of register j = tile
+// t_beg + 64 j + l): the kernels' tile loops then read a count with v_readlane instead of a dependent memory load,
+// which would drain every prefetch in flight.  Ranges are at most 256 tiles (the launchers see to that).
+constexpr int MK_RANGE = 256;
+struct TileK {
+    int r[4];
+};
+__device__ __forceinline__ TileK load_tile_counts(const int32_t* __restrict__ tile_k, int t_beg, int t_end, int lane) {
+    TileK k;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k.r[j] = t_beg + 64 * j + lane < t_end ? tile_k[t_beg + 64 * j + lane] : 0;
+    return k;
+}
+__device__ __forceinline__ int tile_count(const TileK& k, int i) {      // i: wave-uniform index into the range
+    const int l = i & 63, j = i >> 6;
+    const int v0 = __builtin_amdgcn_readlane(k.r[0], l), v1 = __builtin_amdgcn_readlane(k.r[1], l);
+    const int v2 = __builtin_amdgcn_readlane(k.r[2], l), v3 = __builtin_amdgcn_readlane(k.r[3], l);
+    return j == 0 ? v0 : j == 1 ? v1 : j == 2 ? v2 : v3;
+}
+
 // ---- forward ----------------------------------------------------------------------------------------------------
 // Workgroup = 64 rows of z (staged in LDS with an odd pitch and a trailing zero column) x a contiguous range of gene
 // tiles.  Wave w: rows 32 (w & 1) .., tiles t0 + (w >> 1), + 2, ...  Per tile a lane holds the tile's column list in
@@ -137,6 +157,7 @@ __global__ __launch_bounds__(256) void masked_fwd_kernel(const float* __restrict
     const float* zrow = zs + (rb + l31) * ld;
     const int NQ = a.Kmax >> 3;
     const float4* wf = reinterpret_cast<const float4*>(a.Wc + (long long)a.NT * a.Kmax * 32) + lane;
+    const TileK counts = load_tile_counts(a.tile_k, t_beg, t_end, lane);
 
     // (prefetch loads are unconditional and fixed in number - the compiler can then wait for the older tile's
     //  registers with a partial vmcnt instead of draining the queue; out-of-range slots re-read a valid one)
@@ -146,14 +167,9 @@ __global__ __launch_bounds__(256) void masked_fwd_kernel(const float* __restrict
         for (int ch = 0; ch < NCH; ++ch) Cq[ch] = cols[min(64 * ch + lane, a.Kmax - 1)];
 #pragma unroll
         for (int q = 0; q < NCH * 8; ++q) Bq[q] = wf[((long long)t * NQ + min(q, NQ - 1)) * 64];
-        // a block of 16 columns may reach one group of 8 past the tile's count: that group contributes zeros
-        const int nq = (a.tile_k[t] + 7) >> 3;
-#pragma unroll
-        for (int q = 1; q < NCH * 8; q += 2)
-            if (q >= nq) Bq[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     };
     auto compute_tile = [&](int t, const float4 (&Bq)[NCH * 8], const int (&Cq)[NCH]) {
-        const int nq = (a.tile_k[t] + 7) >> 3;
+        const int nq = (tile_count(counts, t - t_beg) + 7) >> 3;
         mg_f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -176,7 +192,9 @@ __global__ __launch_bounds__(256) void masked_fwd_kernel(const float* __restrict
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const float4 b = Bq[2 * p + (i >> 2)];
-                    const float bv = (i & 3) == 0 ? b.x : (i & 3) == 1 ? b.y : (i & 3) == 2 ? b.z : b.w;
+                    float bv = (i & 3) == 0 ? b.x : (i & 3) == 1 ? b.y : (i & 3) == 2 ? b.z : b.w;
+                    // a block of 16 columns may reach one group of 8 past the tile's count: it contributes zeros
+                    if (i >= 4 && 2 * p + 1 >= nq) bv = 0.f;
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p & 1][i], bv, acc, 0, 0, 0);
                 }
             }
@@ -239,14 +257,15 @@ __global__ __launch_bounds__(256) void masked_dx_kernel(const float* __restrict_
     const int row = min(r0 + l31, a.B - 1);
     const bool vec = (ldl & 3) == 0 && (((uintptr_t)dl) & 15) == 0;
 
+    const TileK counts = load_tile_counts(a.tile_k, t_beg, t_end, lane);
     auto next_tile = [&](int t) {               // first tile >= t with active columns
-        while (t < t_end && a.tile_k[t] <= 0) ++t;
+        while (t < t_end && tile_count(counts, t - t_beg) <= 0) ++t;
         return t;
     };
     // (unconditional, fixed number of loads per tile - see the forward kernel.  Genes past G: the B rows of the pack
     //  kernel are zero there, so A only has to be finite and in bounds: offsets are clamped into the row pitch.)
     auto load_tile = [&](int t, DxRegs<NBM>& R) {
-        R.K = a.tile_k[t];
+        R.K = t < t_end ? tile_count(counts, t - t_beg) : 0;
         const int g0 = 32 * t + 16 * half;
         const float* ap = dl + (long long)row * ldl;
         if (vec) {
@@ -498,6 +517,7 @@ int sca_masked_fwd_tiles_per_wg(int B, int NT) {
     const int row_tiles = (B + MF_ROWS - 1) / MF_ROWS;
     int chunks = (512 + row_tiles - 1) / row_tiles;           // ~512 workgroups: two 72 KB tiles of z per CU
     if (chunks > (NT + 1) / 2) chunks = (NT + 1) / 2;          // a workgroup takes at least two tiles (two wave pairs)
+    if (chunks < (NT + MK_RANGE - 1) / MK_RANGE) chunks = (NT + MK_RANGE - 1) / MK_RANGE;
     if (chunks < 1) chunks = 1;
     return (NT + chunks - 1) / chunks;
 }
@@ -506,6 +526,7 @@ int sca_masked_dx_slabs(int B, int NT) {
     int chunks = (256 + row_tiles - 1) / row_tiles;            // one 148 KB workgroup per CU
     if (chunks > NT) chunks = NT;
     if (chunks > 32) chunks = 32;
+    if (chunks < (NT + MK_RANGE - 1) / MK_RANGE) chunks = (NT + MK_RANGE - 1) / MK_RANGE;   // <= 256 tiles per range
     if (chunks < 1) chunks = 1;
     const int per = (NT + chunks - 1) / chunks;
     return (NT + per - 1) / per;
