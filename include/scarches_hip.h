@@ -151,6 +151,15 @@ int sca_mmd_num_partials(int B, int D);
 int sca_mmd_fwd_bwd(const float* feat, int ld, const int32_t* cond, int B, int D, int C, int boundary, float beta,
                     float* Wt, int32_t* counts, double* loss_part, float* grad_slabs, long long slab_stride,
                     void* stream);
+/* The same in two steps, for a caller that knows the minibatch's conditions before its features exist (the weight
+ * table = the partition of the batch by condition, losses.py:255-268): sca_mmd_prepare builds Wt (one small
+ * latency-bound workgroup, issued early on a side stream), sca_mmd_fwd_bwd_prepared evaluates the MMD with it - value
+ * and gradient identical to sca_mmd_fwd_bwd.  Only where sca_mmd_prepared_supported(B, D) == 1 (-2 otherwise). */
+int sca_mmd_prepare(const int32_t* cond, int B, int C, int boundary, float beta, float* Wt, int32_t* counts,
+                    void* stream);
+int sca_mmd_prepared_supported(int B, int D);
+int sca_mmd_fwd_bwd_prepared(const float* feat, int ld, const int32_t* cond, int B, int D, int C, const float* Wt,
+                             double* loss_part, float* grad_slabs, long long slab_stride, void* stream);
 /* Row-block form for data-parallel training (same reference lines; SURVEY 8(e) exception 1: the reference's MMD
  * couples every pair of cells of the global minibatch).  feat / cond hold the all-gathered minibatch [B]; the launch
  * evaluates rows [row_lo, row_lo + row_n) against all B columns: loss partials = the block's share of the MMD (the

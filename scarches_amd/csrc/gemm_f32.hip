@@ -688,9 +688,52 @@ extern "C" int sca_gemm_group_f32(const sca_gemm_job* jobs, int n, void* stream)
     return 0;
 }
 
+// Many slabs of a short vector (the 128 MMD gradient slabs of [B][10]): one thread per (16-byte element, slab group) -
+// 16 groups of a workgroup take every 16th slab each (all their loads in flight at once), their partial sums meet in
+// LDS and are added in group order: a fixed summation order, ~16 x the memory parallelism of the kernel above.
+__global__ __launch_bounds__(256) void slab_reduce_wide_kernel(const float* __restrict__ slabs, int S, long long stride,
+                                                               float* __restrict__ dst, long long n4) {
+    __shared__ float4 part[16][16];
+    const int e = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const long long i4 = (long long)blockIdx.x * 16 + e;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i4 < n4) {
+        const float4* p = reinterpret_cast<const float4*>(slabs) + i4;
+        const long long st4 = stride >> 2;
+        int k = g;
+        for (; k + 48 < S; k += 64) {          // four slabs of this group per trip
+            const float4 v0 = p[k * st4], v1 = p[(k + 16) * st4], v2 = p[(k + 32) * st4], v3 = p[(k + 48) * st4];
+            acc.x += (v0.x + v1.x) + (v2.x + v3.x); acc.y += (v0.y + v1.y) + (v2.y + v3.y);
+            acc.z += (v0.z + v1.z) + (v2.z + v3.z); acc.w += (v0.w + v1.w) + (v2.w + v3.w);
+        }
+        for (; k < S; k += 16) {
+            const float4 v = p[k * st4];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    part[g][e] = acc;
+    __syncthreads();
+    if (g == 0 && i4 < n4) {
+        float4 s = part[0][e];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) {
+            const float4 v = part[q][e];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(dst)[i4] = s;
+    }
+}
+
 extern "C" int sca_splitk_reduce(const float* slabs, int S, long long slab_stride, float* dst, long long n,
                                  void* stream) {
     if (n <= 0) return 0;
+    if (S >= 32 && (n & 3) == 0 && (slab_stride & 3) == 0 && (((uintptr_t)slabs | (uintptr_t)dst) & 15) == 0) {
+        const long long n4 = n >> 2;
+        hipLaunchKernelGGL(slab_reduce_wide_kernel, dim3((unsigned)((n4 + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+                           slabs, S, slab_stride, dst, n4);
+        SCA_CHECK_LAUNCH();
+        return 0;
+    }
     const long long nthreads = (n + 3) / 4;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, slabs, S, slab_stride, dst, n);

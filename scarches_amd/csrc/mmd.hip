@@ -632,6 +632,35 @@ extern "C" int sca_mmd_rows_num_partials(int B, int row_n, int D) {
     return ns * ((row_n + 15) / 16);
 }
 
+// The weight table alone (Wt [C][C], counts [C] optional): one small latency-bound workgroup that only needs the
+// minibatch's conditions - a caller that knows them at the start of the step issues it early, on a side stream, and
+// passes prepared = 1 below so that the MMD launch does not wait for it.
+extern "C" int sca_mmd_prepare(const int32_t* cond, int B, int C, int boundary, float beta, float* Wt, int32_t* counts,
+                               void* stream) {
+    if (B <= 0 || C <= 0) return 0;
+    if (C > 4096) return -2;
+    hipLaunchKernelGGL(mmd_prepare_kernel, dim3(1), dim3(256), 2 * C * sizeof(int), (hipStream_t)stream, cond, B, C,
+                       boundary, beta, Wt, counts, (float*)nullptr, 0LL);
+    SCA_CHECK_LAUNCH();
+    return 0;
+}
+
+static int mmd_rows_launch(const float* feat, int ld, const int32_t* cond, int B, int D, int C, int boundary, float beta,
+                           float* Wt, int32_t* counts, int row_lo, int row_n, double* loss_part, float* grad_slabs,
+                           long long slab_stride, bool prepared, void* stream);
+
+// Whole-minibatch MMD with the weight table already built by sca_mmd_prepare (same cond / B / C / boundary / beta).
+// Only for shapes the row-block kernels serve (sca_mmd_prepared_supported(B, D) == 1: D <= 16 up to 16384 cells).
+extern "C" int sca_mmd_prepared_supported(int B, int D) { return mmd_full_as_rows(B, D) ? 1 : 0; }
+extern "C" int sca_mmd_fwd_bwd_prepared(const float* feat, int ld, const int32_t* cond, int B, int D, int C,
+                                        const float* Wt, double* loss_part, float* grad_slabs, long long slab_stride,
+                                        void* stream) {
+    if (B <= 0 || C <= 0) return 0;
+    if (!mmd_full_as_rows(B, D)) return -2;
+    return mmd_rows_launch(feat, ld, cond, B, D, C, -1, 0.f, const_cast<float*>(Wt), nullptr, 0, B, loss_part, grad_slabs,
+                           slab_stride, true, stream);
+}
+
 // Rows [row_lo, row_lo + row_n) of the gathered minibatch `feat` [B][ld] against all B columns.  The weight table is
 // built from ALL B conditions (rows with a condition outside [0, C) - padding - are ignored), so
 //   sum over the ranks' row blocks of loss_part = the MMD of the whole minibatch, and
@@ -641,13 +670,21 @@ extern "C" int sca_mmd_rows_num_partials(int B, int row_n, int D) {
 extern "C" int sca_mmd_rows_fwd_bwd(const float* feat, int ld, const int32_t* cond, int B, int D, int C, int boundary,
                                     float beta, float* Wt, int32_t* counts, int row_lo, int row_n, double* loss_part,
                                     float* grad_slabs, long long slab_stride, void* stream) {
+    return mmd_rows_launch(feat, ld, cond, B, D, C, boundary, beta, Wt, counts, row_lo, row_n, loss_part, grad_slabs,
+                           slab_stride, false, stream);
+}
+
+static int mmd_rows_launch(const float* feat, int ld, const int32_t* cond, int B, int D, int C, int boundary, float beta,
+                           float* Wt, int32_t* counts, int row_lo, int row_n, double* loss_part, float* grad_slabs,
+                           long long slab_stride, bool prepared, void* stream) {
     if (B <= 0 || C <= 0 || row_n <= 0) return 0;
     if (C > 4096 || D > 1024) return -2;
     if (row_lo < 0 || (long long)row_lo + row_n > B) return -1;
     if (grad_slabs && slab_stride < (long long)row_n * D) return -1;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(mmd_prepare_kernel, dim3(1), dim3(256), 2 * C * sizeof(int), st, cond, B, C, boundary, beta, Wt,
-                       counts, (float*)nullptr, 0LL);
+    if (!prepared)
+        hipLaunchKernelGGL(mmd_prepare_kernel, dim3(1), dim3(256), 2 * C * sizeof(int), st, cond, B, C, boundary, beta,
+                           Wt, counts, (float*)nullptr, 0LL);
     const int ns = sca_mmd_rows_num_slabs(B, row_n, D);
     if (D <= 16) {
         const int nb = (row_n + MMD_T - 1) / MMD_T, jr = mmd_rows_jr(B, row_n);

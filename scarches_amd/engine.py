@@ -41,7 +41,7 @@ _QUERIES = {"sca_gemm_kk_supported", "sca_gemm_kk_splitk_heuristic", "sca_mid_ma
             "sca_gemm_group_max_jobs", "sca_gemm_splitk_heuristic", "sca_mmd_num_slabs", "sca_mmd_num_partials",
             "sca_mmd_rows_num_slabs", "sca_mmd_rows_num_partials", "sca_hsic_workspace_floats",
             "sca_proto_workspace_bytes", "sca_abi_version", "sca_device_name", "sca_masked_dw_slabs",
-            "sca_masked_dx_slabs", "sca_masked_max_cols", "sca_masked_max_width",
+            "sca_masked_dx_slabs", "sca_masked_max_cols", "sca_masked_max_width", "sca_mmd_prepared_supported",
             "sca_masked_fwd_tiles_per_wg"}
 
 
@@ -1002,6 +1002,15 @@ class CVAEEngine:
             if xp_c:
                 _lib.check(L.sca_transpose_scale(P[self.xp_wc].data_ptr(), self.G, self.C, 1.0,
                                                  ws["coffT"].data_ptr(), sa), "cond_transpose")
+            if self._mmd_prepared:
+                # the MMD weight table only needs the conditions: built here, a whole encoder ahead of the MMD launch
+                # (a single latency-bound workgroup, ~25 us at 8192 cells, that used to sit in front of the MMD kernel)
+                bnd = -1 if self.boundary is None else int(self.boundary)
+                _lib.check(L.sca_mmd_prepare(_lib.ptr(self._cond_cur), B, self.C, bnd, self.beta, ws["Wt"].data_ptr(),
+                                             ws["counts"].data_ptr(), sa), "mmd_prepare")
+        Dm = self.Zt if (self.mmd_on == "z" or self.arch == "expimap") else self.dec[0].n_out
+        self._mmd_prepared = bool(self.use_mmd and self.C > 0 and not self._dp_exact() and self._cond_cur is not None
+                                  and L.sca_mmd_prepared_supported(B, Dm))
         self._defer(work)
 
     def _defer_finalize(self, recon_sign, B, accumulate_logs):
@@ -1625,9 +1634,15 @@ class CVAEEngine:
             if ns * B * Dm > ws["mmd_g"].numel():
                 raise RuntimeError("MMD gradient slabs exceed the workspace (%d x %d x %d)" % (ns, B, Dm))
             g_out = ws["mmd_g1"] if ns == 1 else ws["mmd_g"]          # a single slab is the gradient itself
-            _lib.check(L.sca_mmd_fwd_bwd(feat.data_ptr(), Dm, cond_p, B, Dm, C, bnd, self.beta,
-                                         ws["Wt"].data_ptr(), ws["counts"].data_ptr(), ws["mmd_part"].data_ptr(),
-                                         g_out.data_ptr() if compute_grad else None, B * Dm, sa), "mmd")
+            if getattr(self, "_mmd_prepared", False):                  # weight table built in the prologue
+                _lib.check(L.sca_mmd_fwd_bwd_prepared(feat.data_ptr(), Dm, cond_p, B, Dm, C, ws["Wt"].data_ptr(),
+                                                      ws["mmd_part"].data_ptr(),
+                                                      g_out.data_ptr() if compute_grad else None, B * Dm, sa),
+                           "mmd[prepared]")
+            else:
+                _lib.check(L.sca_mmd_fwd_bwd(feat.data_ptr(), Dm, cond_p, B, Dm, C, bnd, self.beta,
+                                             ws["Wt"].data_ptr(), ws["counts"].data_ptr(), ws["mmd_part"].data_ptr(),
+                                             g_out.data_ptr() if compute_grad else None, B * Dm, sa), "mmd")
             if compute_grad and ns > 1:                                # gradient slabs summed off the critical path
                 _lib.check(L.sca_splitk_reduce(ws["mmd_g"].data_ptr(), ns, B * Dm,
                                                ws["mmd_g1"].data_ptr(), B * Dm, sa), "mmd_reduce")

@@ -66,6 +66,23 @@ def test_gemm_modes(lib, M, N, K, mode):
         assert err <= 2e-6 * scale, (S, err, scale)
 
 
+@pytest.mark.parametrize("S,n", [(128, 81920), (33, 1000), (64, 4 * 17), (40, 10240)])
+def test_slab_reduce_many_slabs(lib, S, n):
+    """sca_splitk_reduce with many slabs of a short vector (the MMD gradient slabs): the wide kernel (16 slab groups per
+    workgroup, fixed summation order) against an fp64 sum, bit-identical from run to run."""
+    from scarches_amd import _lib
+    g = torch.Generator().manual_seed(S + n)
+    slabs = dev(torch.randn(S, n, generator=g))
+    out = torch.full((n,), float("nan"), device="cuda")
+    _lib.check(lib.sca_splitk_reduce(slabs.data_ptr(), S, n, out.data_ptr(), n, st()), "reduce")
+    out2 = torch.full((n,), float("nan"), device="cuda")
+    _lib.check(lib.sca_splitk_reduce(slabs.data_ptr(), S, n, out2.data_ptr(), n, st()), "reduce")
+    torch.cuda.synchronize()
+    ref = slabs.double().sum(0)
+    assert (out.double() - ref).abs().max().item() <= 1e-6 * slabs.abs().double().sum(0).max().item()
+    assert torch.equal(out, out2)
+
+
 def test_gemm_bias_and_unaligned(lib):
     from scarches_amd import _lib
     M, N, K = 33, 50, 19           # lda/ldb not multiples of 4 -> scalar staging path
