@@ -153,13 +153,16 @@ int sca_mmd_fwd_bwd(const float* feat, int ld, const int32_t* cond, int B, int D
                     void* stream);
 /* The same in two steps, for a caller that knows the minibatch's conditions before its features exist (the weight
  * table = the partition of the batch by condition, losses.py:255-268): sca_mmd_prepare builds Wt (one small
- * latency-bound workgroup, issued early on a side stream), sca_mmd_fwd_bwd_prepared evaluates the MMD with it - value
- * and gradient identical to sca_mmd_fwd_bwd.  Only where sca_mmd_prepared_supported(B, D) == 1 (-2 otherwise). */
+ * latency-bound workgroup, issued early on a side stream), sca_mmd_fwd_bwd_prepared evaluates rows [row_lo, row_lo +
+ * row_n) of the minibatch against all B columns with it (outputs as for sca_mmd_rows_fwd_bwd below: loss partials =
+ * the block's share, gradient slabs [row_n][D]; row_lo = 0, row_n = B gives value and gradient of sca_mmd_fwd_bwd).
+ * Only where sca_mmd_prepared_supported(B, D) == 1 (-2 otherwise). */
 int sca_mmd_prepare(const int32_t* cond, int B, int C, int boundary, float beta, float* Wt, int32_t* counts,
                     void* stream);
 int sca_mmd_prepared_supported(int B, int D);
 int sca_mmd_fwd_bwd_prepared(const float* feat, int ld, const int32_t* cond, int B, int D, int C, const float* Wt,
-                             double* loss_part, float* grad_slabs, long long slab_stride, void* stream);
+                             int row_lo, int row_n, double* loss_part, float* grad_slabs, long long slab_stride,
+                             void* stream);
 /* Row-block form for data-parallel training (same reference lines; SURVEY 8(e) exception 1: the reference's MMD
  * couples every pair of cells of the global minibatch).  feat / cond hold the all-gathered minibatch [B]; the launch
  * evaluates rows [row_lo, row_lo + row_n) against all B columns: loss partials = the block's share of the MMD (the

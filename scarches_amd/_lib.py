@@ -88,7 +88,7 @@ SIGNATURES = {
     "sca_mmd_fwd_bwd": [P, I, P, I, I, I, I, F, P, P, P, P, LL, P],
     "sca_mmd_prepare": [P, I, I, I, F, P, P, P],
     "sca_mmd_prepared_supported": [I, I],
-    "sca_mmd_fwd_bwd_prepared": [P, I, P, I, I, I, P, P, P, LL, P],
+    "sca_mmd_fwd_bwd_prepared": [P, I, P, I, I, I, P, I, I, P, P, LL, P],
     "sca_mmd_rows_num_slabs": [I, I, I],
     "sca_mmd_rows_num_partials": [I, I, I],
     "sca_mmd_rows_fwd_bwd": [P, I, P, I, I, I, I, F, P, P, I, I, P, P, LL, P],

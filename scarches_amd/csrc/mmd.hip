@@ -649,16 +649,18 @@ static int mmd_rows_launch(const float* feat, int ld, const int32_t* cond, int B
                            float* Wt, int32_t* counts, int row_lo, int row_n, double* loss_part, float* grad_slabs,
                            long long slab_stride, bool prepared, void* stream);
 
-// Whole-minibatch MMD with the weight table already built by sca_mmd_prepare (same cond / B / C / boundary / beta).
+// MMD with the weight table already built by sca_mmd_prepare (same cond / B / C / boundary / beta): rows
+// [row_lo, row_lo + row_n) of the minibatch against all B columns, outputs as for sca_mmd_rows_fwd_bwd (0, B = the whole
+// minibatch; a caller may also cut the minibatch into row blocks and place the launches where the chip has room).
 // Only for shapes the row-block kernels serve (sca_mmd_prepared_supported(B, D) == 1: D <= 16 up to 16384 cells).
 extern "C" int sca_mmd_prepared_supported(int B, int D) { return mmd_full_as_rows(B, D) ? 1 : 0; }
 extern "C" int sca_mmd_fwd_bwd_prepared(const float* feat, int ld, const int32_t* cond, int B, int D, int C,
-                                        const float* Wt, double* loss_part, float* grad_slabs, long long slab_stride,
-                                        void* stream) {
-    if (B <= 0 || C <= 0) return 0;
+                                        const float* Wt, int row_lo, int row_n, double* loss_part, float* grad_slabs,
+                                        long long slab_stride, void* stream) {
+    if (B <= 0 || C <= 0 || row_n <= 0) return 0;
     if (!mmd_full_as_rows(B, D)) return -2;
-    return mmd_rows_launch(feat, ld, cond, B, D, C, -1, 0.f, const_cast<float*>(Wt), nullptr, 0, B, loss_part, grad_slabs,
-                           slab_stride, true, stream);
+    return mmd_rows_launch(feat, ld, cond, B, D, C, -1, 0.f, const_cast<float*>(Wt), nullptr, row_lo, row_n, loss_part,
+                           grad_slabs, slab_stride, true, stream);
 }
 
 // Rows [row_lo, row_lo + row_n) of the gathered minibatch `feat` [B][ld] against all B columns.  The weight table is

@@ -45,6 +45,14 @@ _QUERIES = {"sca_gemm_kk_supported", "sca_gemm_kk_splitk_heuristic", "sca_mid_ma
             "sca_masked_fwd_tiles_per_wg"}
 
 
+# whole-minibatch MMD in two row blocks around the likelihood kernel (fused trVAE step): from this many cells on, first
+# block = this fraction of the rows (0 or 1: one launch).  Off by default: measured on MI355X at 8192 cells the second
+# block beside the output layer's dX / dW GEMMs costs those one-workgroup-per-CU kernels more than the likelihood kernel
+# gains (0.684 ms per step in one launch; 0.794 / 0.779 / 0.763 ms with 0.4 / 0.5 / 0.6).
+MMD_SPLIT_MIN = int(os.environ.get("SCA_MMD_SPLIT_MIN", 4096))
+MMD_SPLIT_FRAC = float(os.environ.get("SCA_MMD_SPLIT_FRAC", 0.0))
+
+
 class _RecordingLib:
     """The C ABI as seen by the engine: every launch goes straight to libscarches_hip.so and, while the engine records
     a launch plan (CVAEEngine.train_step), is also appended to it as (function, argument tuple)."""
@@ -1217,10 +1225,27 @@ class CVAEEngine:
         _lib.check(L.sca_mid_fwd(self._mid_args(B, cond_p, p_drop, eps, masks, pre0=pre0), st), "mid_fwd")
         do_mmd = self.use_mmd and C > 0
         self._n_part = 0
+        # The MMD and the likelihood kernel are both VALU-bound, the GEMMs around them MFMA-bound: from MMD_SPLIT_MIN
+        # cells on the MMD goes in two row blocks - the first beside the output GEMM (and the head of the likelihood),
+        # the second behind the likelihood kernel, beside the dX / dW GEMMs of the output layer - instead of sharing the
+        # vector units with the likelihood kernel for its whole length.
+        n1 = B
+        if (do_mmd and compute_grad and self.overlap and self._mmd_prepared and B >= MMD_SPLIT_MIN
+                and 0.0 < MMD_SPLIT_FRAC < 1.0):
+            n1 = max(256, (int(B * MMD_SPLIT_FRAC) // 256) * 256)
+        mmd_split = n1 < B
         if do_mmd:
-            def mmd_work(sa):
-                self._mmd_launch(sa, ws["z"], Z, self._cond_cur, cond_p, B, compute_grad)
-            self._n_part = self._mmd_partials(B, Z)
+            if mmd_split:
+                nA = L.sca_mmd_rows_num_partials(B, n1, Z)
+                self._n_part = self._grow_mmd_part(nA + L.sca_mmd_rows_num_partials(B, B - n1, Z))
+
+                def mmd_work(sa):
+                    self._mmd_launch(sa, ws["z"], Z, self._cond_cur, cond_p, B, compute_grad, rows=(0, n1))
+            else:
+                self._n_part = self._mmd_partials(B, Z)
+
+                def mmd_work(sa):
+                    self._mmd_launch(sa, ws["z"], Z, self._cond_cur, cond_p, B, compute_grad)
             self._defer(mmd_work)
         ev_side = self._flush()
         Hd = self.dec[-1].n_out
@@ -1242,6 +1267,14 @@ class CVAEEngine:
                                         ws["row_ll"].data_ptr(), ws["dthetaT"].data_ptr(), gob, None,
                                         int(compute_grad), None, None, st), "recon_rows")
             recon_sign = -1.0
+        ev_mmd2 = None
+        if mmd_split:
+            ev_mmd2 = self._next_event()
+
+            def mmd_work2(sa):
+                self._mmd_launch(sa, ws["z"], Z, self._cond_cur, cond_p, B, compute_grad, rows=(n1, B - n1), part_off=nA)
+                self._call(ev_mmd2.record, self._lane_stream(0))
+            self._defer(mmd_work2)
         self._defer_finalize(recon_sign, B, accumulate_logs)
         if not compute_grad:
             self._wait(self._flush())
@@ -1256,9 +1289,13 @@ class CVAEEngine:
                 _lib.check(L.sca_transpose_scale(ws["dthetaT"].data_ptr(), max(C, 1), G, -1.0 / B,
                                                  Gd["theta"].data_ptr(), sa), "transpose_scale")
         self._defer(recon_side, lane=1)         # own stream: starts right behind the likelihood kernel
+        if mmd_split:
+            self._flush()                       # the second MMD block must be enqueued before mid_bwd can wait for it
         sp, S, stride = self._gemm(0, 1, dl, G, P[self.out_w].data_ptr(), Hd, B, Hd, G, st, max_split=self._mid_max_split)
         if do_mmd:
             self._wait(ev_side)
+            if ev_mmd2 is not None:
+                self._call(torch.cuda.current_stream(self.device).wait_event, ev_mmd2)
         _lib.check(L.sca_mid_bwd(self._mid_args(B, cond_p, p_drop, eps, masks, sp, S, stride,
                                                 ws["mmd_g1"].data_ptr() if do_mmd else None, pre0=pre0), st),
                    "mid_bwd")
@@ -1625,17 +1662,31 @@ class CVAEEngine:
         b = self._dp_bufs(-(-int(n_global) // self._dp["world"]), Dm)
         self._dp_stage_gather(b, None, None, 0, Dm, torch.cuda.current_stream(self.device))
 
-    def _mmd_launch(self, sa, feat, Dm, cond_t, cond_p, B, compute_grad):
-        """MMD forward (+ gradient w.r.t. the feature rows into ws['mmd_g1']) on stream `sa`."""
+    def _mmd_launch(self, sa, feat, Dm, cond_t, cond_p, B, compute_grad, rows=None, part_off=0):
+        """MMD forward (+ gradient w.r.t. the feature rows into ws['mmd_g1']) on stream `sa`.  rows = (lo, n): only
+        that row block of the minibatch (prepared weight table required; loss partials from part_off on)."""
         L, ws, C = self.lib, self.ws, self.C
         bnd = -1 if self.boundary is None else int(self.boundary)
+        if rows is not None:
+            lo, n = rows
+            ns = L.sca_mmd_rows_num_slabs(B, n, Dm)
+            if ns * n * Dm > ws["mmd_g"].numel():
+                raise RuntimeError("MMD gradient slabs exceed the workspace (%d x %d x %d)" % (ns, n, Dm))
+            dst = ws["mmd_g1"].data_ptr() + 4 * lo * Dm
+            g_out = dst if ns == 1 else ws["mmd_g"].data_ptr()
+            _lib.check(L.sca_mmd_fwd_bwd_prepared(feat.data_ptr(), Dm, cond_p, B, Dm, C, ws["Wt"].data_ptr(), lo, n,
+                                                  ws["mmd_part"].data_ptr() + 8 * part_off,
+                                                  g_out if compute_grad else None, n * Dm, sa), "mmd[rows]")
+            if compute_grad and ns > 1:
+                _lib.check(L.sca_splitk_reduce(ws["mmd_g"].data_ptr(), ns, n * Dm, dst, n * Dm, sa), "mmd_reduce")
+            return
         if not self._dp_exact():
             ns = L.sca_mmd_num_slabs(B, Dm)
             if ns * B * Dm > ws["mmd_g"].numel():
                 raise RuntimeError("MMD gradient slabs exceed the workspace (%d x %d x %d)" % (ns, B, Dm))
             g_out = ws["mmd_g1"] if ns == 1 else ws["mmd_g"]          # a single slab is the gradient itself
             if getattr(self, "_mmd_prepared", False):                  # weight table built in the prologue
-                _lib.check(L.sca_mmd_fwd_bwd_prepared(feat.data_ptr(), Dm, cond_p, B, Dm, C, ws["Wt"].data_ptr(),
+                _lib.check(L.sca_mmd_fwd_bwd_prepared(feat.data_ptr(), Dm, cond_p, B, Dm, C, ws["Wt"].data_ptr(), 0, B,
                                                       ws["mmd_part"].data_ptr(),
                                                       g_out.data_ptr() if compute_grad else None, B * Dm, sa),
                            "mmd[prepared]")
@@ -1669,6 +1720,12 @@ class CVAEEngine:
         if compute_grad and ns > 1:
             _lib.check(L.sca_splitk_reduce(b["slabs"].data_ptr(), ns, B * Dm, ws["mmd_g1"].data_ptr(), B * Dm, sa),
                        "mmd_reduce[dp]")
+
+    def _grow_mmd_part(self, n):
+        if self.ws["mmd_part"].numel() < n:
+            self._invalidate()
+            self.ws["mmd_part"] = torch.zeros(n, dtype=torch.float64, device=self.device)
+        return n
 
     def _mmd_partials(self, B, Dm):
         """Number of loss partials the MMD launch of this step writes (ws['mmd_part'] is grown to hold them)."""
