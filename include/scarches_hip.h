@@ -163,6 +163,10 @@ int sca_mmd_prepared_supported(int B, int D);
 int sca_mmd_fwd_bwd_prepared(const float* feat, int ld, const int32_t* cond, int B, int D, int C, const float* Wt,
                              int row_lo, int row_n, double* loss_part, float* grad_slabs, long long slab_stride,
                              void* stream);
+/* Tuning hook, process-wide: 0 = vector-ALU row-block kernel (default), 1 = the form that computes the pair distances
+ * and the owner gradients with v_mfma_f32_16x16x4_f32 (D <= 10; same outputs, different slab / partial counts - call
+ * before sizing workspaces with sca_mmd_*_num_slabs / _num_partials).  Returns the previous selection. */
+int sca_mmd_select_form(int form);
 /* Row-block form for data-parallel training (same reference lines; SURVEY 8(e) exception 1: the reference's MMD
  * couples every pair of cells of the global minibatch).  feat / cond hold the all-gathered minibatch [B]; the launch
  * evaluates rows [row_lo, row_lo + row_n) against all B columns: loss partials = the block's share of the MMD (the

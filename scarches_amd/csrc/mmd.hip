@@ -428,6 +428,194 @@ __global__ __launch_bounds__(256) void mmd_small_kernel(const float* __restrict_
     }
 }
 
+// ---- MFMA form of the row-block kernel (round 2) -------------------------------------------------------------------
+// Same outputs as mmd_small_kernel<D, ROWS = true> (every ordered pair of the launch's rows against all B columns), with
+// the two inner products of a pair moved from the vector ALU to v_mfma_f32_16x16x4_f32:
+//   * d2 of a 16 x 16 tile of (partner m, owner n) pairs = x'_m . y'_n with the augmented vectors
+//       x' = [-2 x, |x|^2, 1],  y' = [y, 1, |y|^2]      (K = D + 2 <= 12: three MFMAs);
+//     the result lands in the accumulator layout: lane (n = l % 16, kg = l / 16) holds partners m = 4 kg + r, r < 4 -
+//     four independent pairs per lane, exactly what rbf19<4> wants.  |x|^2 + |y|^2 - 2 x.y cancels for near points, so
+//     a tile in which any pair has d2 < 2 (the diagonal tile, near-coincident cells) recomputes its d2 from differences
+//     on the vector ALU - far pairs only feed kernels whose derivative is small (dK = Kp dd2 with Kp ~ 0.1 at d2 ~ 20:
+//     an absolute 1e-5 in d2 is 1e-7 of K);
+//   * the gradient of the OWNER point, g_n = sum_m coef_mn (y_n - x_m) = y_n S_n - T_n with
+//       [T_n ; S_n] = sum_m [x_m ; 1] coef_mn:
+//     the accumulator registers of the tile ARE the B operand of that product (register r of lane (n, kg) = coef of
+//     partner 4 kg + r, i.e. B[k = kg][n] of MFMA r), A = [x ; 1]^T from LDS - four MFMAs per tile whose output
+//     accumulates over ALL partner tiles of the workgroup's range in four registers: no per-pair gradient FMAs, no
+//     parked coefficients, and one slab per partner range (8 - 16 instead of 128).
+// A wave owns 16 points (lanes replicate them over the four partner groups), a workgroup 64, and walks its partner
+// range in staged chunks of 256 (x', [x ; 1] and the conditions in LDS).  The weight Wt[c_n][c_m] is fetched once per
+// run of equal partner conditions (condition-sorted minibatches: one load per ~25 tiles); tiles that straddle two runs
+// look their four weights up individually.
+typedef float mm_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int MM_CH = 256;      // partners per staged chunk
+constexpr int MM_LD = 12;       // floats per staged partner row (features 0..9, then the two augmentation slots)
+
+template <int DMAX>
+__global__ __launch_bounds__(256) void mmd_mfma_kernel(const float* __restrict__ z, int ldz,
+                                                       const int32_t* __restrict__ cond, int B, int D, int C,
+                                                       const float* __restrict__ Wt, double* __restrict__ loss_part,
+                                                       float* __restrict__ grad, long long slab_stride, int per_range,
+                                                       int row_lo, int row_n) {
+    static_assert(DMAX <= 10, "augmented vectors must fit K = 12");
+    __shared__ __attribute__((aligned(16))) float xq[MM_CH * MM_LD];      // x' = [-2 x, |x|^2, 1]
+    __shared__ __attribute__((aligned(16))) float xa[MM_CH * MM_LD];      // [x, 1, 0]
+    __shared__ int cj[MM_CH];
+    __shared__ double redd[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n16 = lane & 15, kg = lane >> 4;
+    // ---- the wave's 16 owner points
+    const int il = (blockIdx.x * 4 + w) * 16 + n16;            // row within the launch's row range
+    const bool act = il < row_n;
+    const int io = row_lo + min(il, row_n - 1);
+    float y[DMAX];
+    float n2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) {
+        y[k] = k < D ? z[(long long)io * ldz + k] : 0.f;
+        n2 = fmaf(y[k], y[k], n2);
+    }
+    const int co = act ? cond[io] : -1;
+    const bool ok = co >= 0 && co < C;
+    const float* wrow = Wt + (long long)(ok ? co : 0) * C;
+    // B fragments of the d2 product: y'[n][4 s + kg], s = 0..2
+    float yb[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int c = 4 * s + kg;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k)
+            if (k == c) v = y[k];
+        if (c == 10) v = 1.0f;
+        if (c == 11) v = n2;
+        yb[s] = v;
+    }
+    mm_f32x4 gacc = {0.f, 0.f, 0.f, 0.f};      // [T ; S] rows 4 kg + r of this owner
+    float gv[DMAX];                              // gradient share of near tiles (this lane's partners)
+#pragma unroll
+    for (int k = 0; k < DMAX; ++k) gv[k] = 0.f;
+    float lsum = 0.f;
+    int c_run = -2;                              // partner condition of the cached weight
+    float w_run = 0.f;
+    const int j_beg = blockIdx.y * per_range, j_end = min(B, j_beg + per_range);
+    for (int j0 = j_beg; j0 < j_end; j0 += MM_CH) {
+        const int nj = min(j_end - j0, MM_CH);
+        __syncthreads();                         // previous chunk fully consumed
+        {
+            const int t = threadIdx.x;
+            float v[DMAX], q = 0.f;
+            const bool in = t < nj;
+#pragma unroll
+            for (int k = 0; k < DMAX; ++k) {
+                v[k] = (in && k < D) ? z[(long long)(j0 + t) * ldz + k] : 0.f;
+                q = fmaf(v[k], v[k], q);
+            }
+#pragma unroll
+            for (int k = 0; k < 10; ++k) {
+                xq[t * MM_LD + k] = k < DMAX ? -2.0f * v[k < DMAX ? k : 0] : 0.f;
+                xa[t * MM_LD + k] = k < DMAX ? v[k < DMAX ? k : 0] : 0.f;
+            }
+            xq[t * MM_LD + 10] = q;  xq[t * MM_LD + 11] = 1.0f;
+            xa[t * MM_LD + 10] = 1.0f; xa[t * MM_LD + 11] = 0.f;
+            cj[t] = in ? cond[j0 + t] : -1;
+        }
+        __syncthreads();
+        const int ntile = (nj + 15) >> 4;
+        for (int tile = 0; tile < ntile; ++tile) {
+            const int m0 = tile * 16;
+            // ---- d2 tile: A[m = l % 16][k = l / 16] = x'[m0 + m][4 s + kg]
+            mm_f32x4 dd = {0.f, 0.f, 0.f, 0.f};
+            const float* xr = &xq[(m0 + n16) * MM_LD + kg];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) dd = __builtin_amdgcn_mfma_f32_16x16x4f32(xr[4 * s], yb[s], dd, 0, 0, 0);
+            float d2[4] = {fmaxf(dd[0], 0.f), fmaxf(dd[1], 0.f), fmaxf(dd[2], 0.f), fmaxf(dd[3], 0.f)};
+            const bool near = d2[0] < 2.0f || d2[1] < 2.0f || d2[2] < 2.0f || d2[3] < 2.0f;
+            const bool near_tile = __ballot(near) != 0ull;
+            if (near_tile) {                     // exact differences for this tile (diagonal tile, coincident cells)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* xm = &xa[(m0 + 4 * kg + r) * MM_LD];
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < DMAX; ++k) {
+                        const float df = y[k] - xm[k];
+                        acc = fmaf(df, df, acc);
+                    }
+                    d2[r] = acc;
+                }
+            }
+            v2f KK[4];
+            rbf19<4>(d2, KK);
+            // ---- weights: one per run of equal partner conditions, else per pair
+            const int c0 = cj[m0];
+            const bool uni = __ballot(lane < 16 && cj[m0 + lane] != c0) == 0ull;
+            float wq[4];
+            if (uni) {
+                if (c0 != c_run) {
+                    c_run = c0;
+                    w_run = (ok && c0 >= 0 && c0 < C) ? wrow[c0] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) wq[r] = w_run;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int c2 = cj[m0 + 4 * kg + r];
+                    wq[r] = (ok && c2 >= 0 && c2 < C) ? wrow[c2] : 0.f;
+                }
+            }
+            mm_f32x4 coef;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                lsum = fmaf(wq[r], KK[r].x, lsum);
+                coef[r] = -4.0f * wq[r] * KK[r].y;
+            }
+            if (near_tile) {
+                // near pairs carry huge coefficients (narrow kernels) times tiny differences: y S - T would cancel
+                // catastrophically (the pair of a point with itself must contribute exactly 0), so these tiles
+                // accumulate coef (y - x) from differences on the vector ALU and stay out of the MFMA product
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float* xm = &xa[(m0 + 4 * kg + r) * MM_LD];
+#pragma unroll
+                    for (int k = 0; k < DMAX; ++k) gv[k] = fmaf(coef[r], y[k] - xm[k], gv[k]);
+                    coef[r] = 0.f;
+                }
+            }
+            // ---- [T ; S] += [x ; 1]^T coef: MFMA r contracts partners 4 k + r, A[i' = l % 16][k = l / 16]
+            const float* ar = &xa[(m0 + 4 * kg) * MM_LD + min(n16, 11)];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                gacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[r * MM_LD], coef[r], gacc, 0, 0, 0);
+        }
+    }
+    const double tot = block_sum_d((double)lsum, redd);
+    if (threadIdx.x == 0) loss_part[blockIdx.y * gridDim.x + blockIdx.x] = tot;
+    if (grad) {
+        // g_n[f] = y_n[f] S_n - T_n[f];  S_n = row 10 = register 2 of the lane (n, kg = 2)
+        const float S = __shfl(gacc[2], 32 + n16, 64);
+#pragma unroll
+        for (int k = 0; k < DMAX; ++k) {          // near-tile shares of the four partner groups of an owner
+            gv[k] += __shfl_xor(gv[k], 16, 64);
+            gv[k] += __shfl_xor(gv[k], 32, 64);
+        }
+        float* gs = grad + (long long)blockIdx.y * slab_stride + (long long)il * D;
+        if (act) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int f = 4 * kg + r;
+                float yf = 0.f, gn = 0.f;
+#pragma unroll
+                for (int k = 0; k < DMAX; ++k)
+                    if (k == f) { yf = y[k]; gn = gv[k]; }
+                if (f < D) gs[f] = fmaf(yf, S, -gacc[r]) + gn;
+            }
+        }
+    }
+}
+
 // Any feature dimension (MMD on the first decoder layer, mmd_on='y'): 16 x 16 pair tiles through LDS.
 // A workgroup owns 16 rows i and a chunk of columns j; the gradient for its rows is accumulated in registers.
 constexpr int MMD_GD = 64;    // feature chunk staged per pass
@@ -604,6 +792,32 @@ extern "C" int sca_mmd_fwd_bwd(const float* feat, int ld, const int32_t* cond, i
 // from 4096 columns on.  Short workgroups interleave better with the likelihood kernel that shares the chip with the
 // MMD inside the step (cfg2 step at B = 8192: 0.711 ms with 8 chunks = 1024 workgroups, 0.703 / 0.684 / 0.673 / 0.693
 // with 6 / 3 / 2 / 1; at B = 4096: 0.411 with 2, 0.423 with 1, 0.416 with 4; B = 2048: 1 and 2 equal).
+// MFMA form (D <= 10): partners per workgroup range - about 2048 workgroups of 64 owners, whole staged chunks
+// Off by default: measured on MI355X it is slower than the vector-ALU form (B = 8192: 175 vs 158 us alone, step 0.746 vs
+// 0.684 ms).  PMC says why: both forms issue the same ~228 vector instructions per 256 pairs (rbf19<4> is ~170 of
+// them and stays; the accumulator reads, clamps, weight selects and operand moves around the MFMAs cost what the
+// difference / gradient FMAs cost before) at one vector instruction per ~4.4 cycles and SIMD - the kernel is bound by
+// the instruction count, not by the FMA work the matrix unit took over.  sca_mmd_select_form(1) / SCA_MMD_MFMA=1 select
+// it (tests, A/B runs); the choice is process-wide and must not change while launches are being sized.
+static int g_mmd_form = [] { const char* v = getenv("SCA_MMD_MFMA"); return (v && atoi(v) != 0) ? 1 : 0; }();
+extern "C" int sca_mmd_select_form(int form) {
+    const int prev = g_mmd_form;
+    if (form == 0 || form == 1) g_mmd_form = form;
+    return prev;
+}
+static bool mmd_use_mfma(int D) { return g_mmd_form == 1 && D <= 10; }
+static int mmd_mfma_per_range(int B, int row_n) {
+    const long long ob = (row_n + 63) / 64;
+    static const int wg_env = [] { const char* v = getenv("SCA_MMD_MFMA_WG"); return v ? atoi(v) : 2048; }();
+    long long S = (wg_env + ob - 1) / ob;
+    const long long smax = (B + MM_CH - 1) / MM_CH;
+    if (S > smax) S = smax;
+    if (S > 32) S = 32;
+    if (S < 1) S = 1;
+    long long per = (B + S - 1) / S;
+    per = ((per + MM_CH - 1) / MM_CH) * MM_CH;
+    return (int)per;
+}
 static int mmd_rows_jr(int B, int row_n) {
     const long long nb = (row_n + MMD_T - 1) / MMD_T, nbc = (B + MMD_TC - 1) / MMD_TC;
     long long jr = ((nb + 3) / 4) * nbc / 4096;
@@ -616,6 +830,10 @@ static int mmd_rows_jr(int B, int row_n) {
 }
 extern "C" int sca_mmd_rows_num_slabs(int B, int row_n, int D) {
     if (B <= 0 || row_n <= 0) return 0;
+    if (mmd_use_mfma(D)) {
+        const int per = mmd_mfma_per_range(B, row_n);
+        return (B + per - 1) / per;
+    }
     if (D <= 16) {
         const int nbc = (B + MMD_TC - 1) / MMD_TC, jr = mmd_rows_jr(B, row_n);
         return (nbc + jr - 1) / jr;
@@ -628,6 +846,7 @@ extern "C" int sca_mmd_rows_num_slabs(int B, int row_n, int D) {
 extern "C" int sca_mmd_rows_num_partials(int B, int row_n, int D) {
     if (B <= 0 || row_n <= 0) return 0;
     const int ns = sca_mmd_rows_num_slabs(B, row_n, D);
+    if (mmd_use_mfma(D)) return ((row_n + 63) / 64) * ns;
     if (D <= 16) return (((row_n + MMD_T - 1) / MMD_T + 3) / 4) * ns;
     return ns * ((row_n + 15) / 16);
 }
@@ -688,7 +907,11 @@ static int mmd_rows_launch(const float* feat, int ld, const int32_t* cond, int B
         hipLaunchKernelGGL(mmd_prepare_kernel, dim3(1), dim3(256), 2 * C * sizeof(int), st, cond, B, C, boundary, beta,
                            Wt, counts, (float*)nullptr, 0LL);
     const int ns = sca_mmd_rows_num_slabs(B, row_n, D);
-    if (D <= 16) {
+    if (mmd_use_mfma(D)) {
+        dim3 grid((row_n + 63) / 64, ns);
+        hipLaunchKernelGGL((mmd_mfma_kernel<10>), grid, dim3(256), 0, st, feat, ld, cond, B, D, C, Wt, loss_part,
+                           grad_slabs, slab_stride, mmd_mfma_per_range(B, row_n), row_lo, row_n);
+    } else if (D <= 16) {
         const int nb = (row_n + MMD_T - 1) / MMD_T, jr = mmd_rows_jr(B, row_n);
         dim3 grid((nb + 3) / 4, ns);
         if (D == 10)

@@ -41,7 +41,7 @@ _QUERIES = {"sca_gemm_kk_supported", "sca_gemm_kk_splitk_heuristic", "sca_mid_ma
             "sca_gemm_group_max_jobs", "sca_gemm_splitk_heuristic", "sca_mmd_num_slabs", "sca_mmd_num_partials",
             "sca_mmd_rows_num_slabs", "sca_mmd_rows_num_partials", "sca_hsic_workspace_floats",
             "sca_proto_workspace_bytes", "sca_abi_version", "sca_device_name", "sca_masked_dw_slabs",
-            "sca_masked_dx_slabs", "sca_masked_max_cols", "sca_masked_max_width", "sca_mmd_prepared_supported",
+            "sca_masked_dx_slabs", "sca_masked_max_cols", "sca_masked_max_width", "sca_mmd_prepared_supported", "sca_mmd_select_form",
             "sca_masked_fwd_tiles_per_wg"}
 
 

@@ -170,6 +170,59 @@ def test_mmd_golden(lib, key):
         assert rel_err(grad, z[f"mmd_{key}_grad"]) < 5e-5
 
 
+@pytest.fixture
+def mfma_form(lib):
+    """The MFMA form of the row-block MMD kernel (opt-in tuning hook), restored afterwards."""
+    prev = lib.sca_mmd_select_form(1)
+    yield
+    torch.cuda.synchronize()
+    lib.sca_mmd_select_form(prev)
+
+
+@pytest.mark.parametrize("key", list("abcde"))
+def test_mmd_golden_mfma_form(lib, key, mfma_form):
+    """The same golden vectors through mmd_mfma_kernel (pair distances and owner gradients on v_mfma_f32_16x16x4_f32,
+    near tiles - every tile of these small batches - on exact differences)."""
+    test_mmd_golden(lib, key)
+
+
+@pytest.mark.parametrize("B,D,C", [(1500, 10, 7), (4096, 10, 20), (777, 6, 3)])
+def test_mmd_mfma_form_far_tiles_vs_fp64(lib, mfma_form, B, D, C):
+    """Sizes at which most 16 x 16 tiles are far (d2 >= 2 everywhere: distances from the augmented-vector MFMA, owner
+    gradients from the accumulator-as-operand MFMA) against a plain fp64 evaluation of the reference's formula
+    (losses.py:166-270): value rel 1e-5, gradient 1e-5 of its maximum."""
+    from scarches_amd import _lib
+    g = torch.Generator().manual_seed(B + D)
+    z = torch.randn(B, D, generator=g) * 1.3
+    lab = torch.sort(torch.randint(0, C, (B,), generator=g))[0].to(torch.int32)
+    ns, npart = lib.sca_mmd_num_slabs(B, D), lib.sca_mmd_num_partials(B, D)
+    Wt = torch.empty(C * C, device="cuda")
+    part = torch.zeros(npart, dtype=torch.float64, device="cuda")
+    slabs = torch.full((ns, B, D), float("nan"), device="cuda")
+    _lib.check(lib.sca_mmd_fwd_bwd(dev(z).data_ptr(), D, dev(lab, torch.int32).data_ptr(), B, D, C, -1, 1.0,
+                                   Wt.data_ptr(), None, part.data_ptr(), slabs.data_ptr(), B * D, st()), "mmd")
+    torch.cuda.synchronize()
+    alphas = torch.tensor([1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 1e-1, 1, 5, 10, 15, 20, 25, 30, 35, 100, 1e3, 1e4, 1e5, 1e6],
+                          dtype=torch.float64, device="cuda")
+    zz = z.double().cuda().requires_grad_(True)
+    labd = lab.cuda()
+
+    def K(x, y):
+        d = ((x[:, None] - y[None]) ** 2).sum(2)
+        return sum(torch.exp(-d / (2 * a)) for a in alphas)
+    parts = [zz[labd == c] for c in range(C)]
+    tot = 0
+    for a in range(C):
+        for b in range(a):
+            if len(parts[a]) and len(parts[b]):
+                tot = tot + K(parts[a], parts[a]).mean() + K(parts[b], parts[b]).mean() - 2 * K(parts[a], parts[b]).mean()
+    tot.backward()
+    val = part.sum().item()
+    assert abs(val - tot.item()) <= 1e-5 * abs(tot.item()) + 1e-6
+    got = slabs.double().sum(0)
+    assert float((got - zz.grad).abs().max()) <= 1e-5 * float(zz.grad.abs().max())
+
+
 @pytest.mark.parametrize("key", list("abcde"))
 def test_mmd_row_blocks_golden(lib, key):
     """sca_mmd_rows_fwd_bwd (row block x all columns, the data-parallel form): ragged row blocks of the golden
