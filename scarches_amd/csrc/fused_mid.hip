@@ -67,12 +67,14 @@ typedef struct {
 
 #ifdef SCA_MID_DEBUG
 __device__ long long g_mid_dbg[64];
-#define DBG(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_mid_dbg[i] = wall_clock64(); } while (0)
+#define DBG(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_mid_dbg[i] = wall_clock64(); g_mid_dbg[32 + (i)] = clock64(); } } while (0)
 #else
 #define DBG(i)
 #endif
 
 namespace {
+
+__device__ __attribute__((aligned(16))) float g_mid_blank[4];   // what an unconditional prefetch reads for an absent operand
 
 constexpr int TM = 32;          // cells per workgroup
 constexpr int KC = 64;          // reduction chunk staged in LDS (64 deep: half as many exposed weight-fetch latencies)
@@ -83,38 +85,50 @@ constexpr int NST = KC * 128 / 256;   // staged weight values per thread and chu
 // out[r][j] = sum_i act[r][i] * M(i, j), r < TM, j < J, i < I.
 //   FWD : M(i, j) = W[j*ldW + i]   (y = x W^T: i = input feature, j = output unit)
 //   !FWD: M(i, j) = W[i*ldW + j]   (dx = da W: i = output unit, j = input feature)
+// Every prefetch load is UNCONDITIONAL - out-of-range lanes read a clamped address - and its value stays RAW in its
+// register until the consumer (stage_store, the row epilogues) drops or uses it: a fixed number of loads in flight
+// lets the compiler wait for an older prefetch with an exact vmcnt, and no instruction between issue and consumer
+// touches the value, so the wait really sits at the consumer.  (A conditional load, or a select / multiply right after
+// it, puts the full L2 latency behind every issue: 3 - 7 us per weight chunk when 256 workgroups ask for the same lines.)
 template <bool FWD>
 __device__ __forceinline__ void stage_load(float (&v)[NST], const float* __restrict__ W, int ldW, int i0, int in_,
                                            int j0, int jn) {
+    const int tid = threadIdx.x;
+    if (FWD) {
+        const int iic = min(tid & (KC - 1), in_ - 1);
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            const int jjc = min(tid / KC + (256 / KC) * q, jn - 1);
+            v[q] = W[(long long)(j0 + jjc) * ldW + i0 + iic];
+        }
+    } else {
+        const int jjc = min(tid & 127, jn - 1);
+#pragma unroll
+        for (int q = 0; q < NST; ++q) {
+            const int iic = min((tid >> 7) + 2 * q, in_ - 1);
+            v[q] = W[(long long)(i0 + iic) * ldW + j0 + jjc];
+        }
+    }
+}
+
+// Chunk rows past in_ and columns past jn are stored as zeros (the raw registers hold clamped re-reads there).
+template <bool FWD>
+__device__ __forceinline__ void stage_store(const float (&v)[NST], float* __restrict__ Ms, int in_, int jn) {
     const int tid = threadIdx.x;
     if (FWD) {
         const int ii = tid & (KC - 1);
 #pragma unroll
         for (int q = 0; q < NST; ++q) {
             const int jj = tid / KC + (256 / KC) * q;
-            v[q] = (ii < in_ && jj < jn) ? W[(long long)(j0 + jj) * ldW + i0 + ii] : 0.f;
+            Ms[ii * MS_LD + jj] = (ii < in_ && jj < jn) ? v[q] : 0.f;
         }
     } else {
         const int jj = tid & 127;
 #pragma unroll
         for (int q = 0; q < NST; ++q) {
             const int ii = (tid >> 7) + 2 * q;
-            v[q] = (ii < in_ && jj < jn) ? W[(long long)(i0 + ii) * ldW + j0 + jj] : 0.f;
+            Ms[ii * MS_LD + jj] = (ii < in_ && jj < jn) ? v[q] : 0.f;
         }
-    }
-}
-
-template <bool FWD>
-__device__ __forceinline__ void stage_store(const float (&v)[NST], float* __restrict__ Ms) {
-    const int tid = threadIdx.x;
-    if (FWD) {
-        const int ii = tid & (KC - 1);
-#pragma unroll
-        for (int q = 0; q < NST; ++q) Ms[ii * MS_LD + tid / KC + (256 / KC) * q] = v[q];
-    } else {
-        const int jj = tid & 127;
-#pragma unroll
-        for (int q = 0; q < NST; ++q) Ms[((tid >> 7) + 2 * q) * MS_LD + jj] = v[q];
     }
 }
 
@@ -123,32 +137,64 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // One v_mfma_f32_32x32x2_f32 output block per wave: wave w owns columns [32w, 32w+32) of the current 128-column block,
 // all TM = 32 rows.  Operand layout of the instruction: A lane (l31, half) = act[l31][k + half], B lane (l31, half) =
 // M(k + half, l31); accumulator register r of lane (l31, half) = out[(r & 3) + 8 (r >> 2) + 4 half][l31].
+// First weight chunk of a tile_gemm, requested early: the caller issues it BEFORE the row epilogue (or tile load) that
+// precedes the GEMM, so its L2 / HBM latency is hidden behind that phase instead of opening every GEMM.
+template <bool FWD>
+__device__ __forceinline__ void tile_gemm_prefetch(float (&nxt)[NST], const float* __restrict__ W, int ldW, int I, int J) {
+    stage_load<FWD>(nxt, W, ldW, 0, min(KC, I), 0, min(128, J));
+}
+
 template <bool FWD>
 __device__ __forceinline__ void tile_gemm(const float* __restrict__ act, int lda, int I, const float* __restrict__ W,
-                                          int ldW, int J, float* __restrict__ out, int ldo, float* __restrict__ Ms) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, l31 = lane & 31, half = lane >> 5;
+                                          int ldW, int J, float* __restrict__ out, int ldo, float* __restrict__ Ms,
+                                          float (&nxt)[NST]) {
+    // `nxt` arrives holding chunk (i0 = 0, j0 = 0) - tile_gemm_prefetch - and is consumed
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31, half = lane >> 5;
     for (int j0 = 0; j0 < J; j0 += 128) {
         const int jn = min(128, J - j0);
+        const bool has_cols = 32 * w < jn;          // narrow outputs (heads: 2 Z columns) leave whole waves without work
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        float nxt[NST];                             // next weight chunk, in flight while the current one is consumed
-        stage_load<FWD>(nxt, W, ldW, 0, min(KC, I), j0, jn);
+        if (j0 > 0) stage_load<FWD>(nxt, W, ldW, 0, min(KC, I), j0, jn);
         for (int i0 = 0; i0 < I; i0 += KC) {
             __syncthreads();                         // previous chunk consumed (and `act` complete on first entry)
-            stage_store<FWD>(nxt, Ms);
+            if (FWD && i0 == 0) DBG(16);
+            stage_store<FWD>(nxt, Ms, min(KC, I - i0), jn);
+            if (FWD && i0 == 0) DBG(17);
             __syncthreads();
+            if (FWD && i0 == 0) DBG(18);
             if (i0 + KC < I) stage_load<FWD>(nxt, W, ldW, i0 + KC, min(KC, I - i0 - KC), j0, jn);
+            if (FWD && i0 == 0) DBG(19);
+            if (!has_cols) continue;
             const float* ap = act + l31 * lda + i0 + half;
             const float* bp = Ms + half * MS_LD + 32 * w + l31;
-            float av[KC / 2], bv[KC / 2];
+            const int kn = (min(KC, I - i0) + 1) >> 1;      // k pairs that hold data (z -> first decoder layer: 5 of 32)
+            if (kn == KC / 2) {
+                float av[KC / 2], bv[KC / 2];
 #pragma unroll
-            for (int kk = 0; kk < KC / 2; ++kk) {
-                av[kk] = ap[2 * kk];
-                bv[kk] = bp[2 * kk * MS_LD];
+                for (int kk = 0; kk < KC / 2; ++kk) {
+                    av[kk] = ap[2 * kk];
+                    bv[kk] = bp[2 * kk * MS_LD];
+                }
+#pragma unroll
+                for (int kk = 0; kk < KC / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
+#ifdef SCA_MID_DEBUG
+                if (FWD && i0 == 0) { asm volatile("s_nop 0" :: "v"(acc)); DBG(20); }
+#endif
+            } else {
+                // (columns of `act` and rows of the staged chunk past the data are zero: rounding kn up to 8 is harmless)
+                for (int k8 = 0; k8 < kn; k8 += 8) {
+                    float av[8], bv[8];
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        av[kk] = ap[2 * (k8 + kk)];
+                        bv[kk] = bp[2 * (k8 + kk) * MS_LD];
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
+                }
             }
-#pragma unroll
-            for (int kk = 0; kk < KC / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
         }
         const int n = 32 * w + l31;
         if (n < jn) {
@@ -181,28 +227,50 @@ __device__ __forceinline__ float row8_sum(float v) {      // sum over the 8 cons
 __device__ __forceinline__ void load_tile(float* __restrict__ dst, int ld, const float* __restrict__ src, int S,
                                           long long stride, int r0, int B, int width, int Kp) {
     if ((width & 3) == 0 && ((uintptr_t)src & 15) == 0 && (stride & 3) == 0) {
+        // NP positions of a thread x two slabs = 8 independent 16-byte loads in flight (a serial position / slab walk pays
+        // one HBM latency per load: 11 us for the four slabs of the first layer at B = 8192)
+        constexpr int NP = 4;
         const int w4 = Kp >> 2;
-        for (int t = threadIdx.x; t < TM * w4; t += 256) {
-            const int r = t / w4, k = (t - r * w4) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < width && r0 + r < B) {
-                const float* p = src + (long long)(r0 + r) * width + k;
-                v = *reinterpret_cast<const float4*>(p);
-                int q = 1;
-                for (; q + 3 < S; q += 4) {                 // four slab loads in flight
-                    float4 u[4];
+        for (int t0 = threadIdx.x; t0 < TM * w4; t0 += 256 * NP) {
+            const float* p[NP];
+            float4 v[NP];
+            int off[NP];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) u[i] = *reinterpret_cast<const float4*>(p + (q + i) * stride);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { v.x += u[i].x; v.y += u[i].y; v.z += u[i].z; v.w += u[i].w; }
-                }
-                for (; q < S; ++q) {
-                    const float4 u = *reinterpret_cast<const float4*>(p + q * stride);
-                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-                }
+            for (int i = 0; i < NP; ++i) {
+                const int t = t0 + 256 * i;
+                const int r = t / w4, k = (t - r * w4) * 4;
+                const bool ok = t < TM * w4 && k < width && r0 + r < B;
+                p[i] = ok ? src + (long long)(r0 + r) * width + k : nullptr;
+                off[i] = t < TM * w4 ? r * ld + k : -1;
+                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            float* d = dst + r * ld + k;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            int q = 0;
+            for (; q + 1 < S; q += 2) {
+                float4 u[NP][2];
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        u[i][h] = p[i] ? *reinterpret_cast<const float4*>(p[i] + (q + h) * stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) { v[i].x += u[i][h].x; v[i].y += u[i][h].y; v[i].z += u[i][h].z; v[i].w += u[i][h].w; }
+            }
+            if (q < S) {
+                float4 u[NP];
+#pragma unroll
+                for (int i = 0; i < NP; ++i)
+                    u[i] = p[i] ? *reinterpret_cast<const float4*>(p[i] + q * stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < NP; ++i) { v[i].x += u[i].x; v[i].y += u[i].y; v[i].z += u[i].z; v[i].w += u[i].w; }
+            }
+#pragma unroll
+            for (int i = 0; i < NP; ++i)
+                if (off[i] >= 0) {
+                    float* d = dst + off[i];
+                    d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+                }
         }
     } else {
         for (int t = threadIdx.x; t < TM * Kp; t += 256) {
@@ -220,14 +288,36 @@ __device__ __forceinline__ void load_tile(float* __restrict__ dst, int ld, const
 // 8 threads of a row touch 128 contiguous bytes per group (16-byte HBM stores).  All HBM reads of the epilogue (bias,
 // condition column) are issued up front and the row lives in registers from then on: the chain is latency-bound, not
 // arithmetic-bound.
+// The additive terms of a row epilogue (bias + condition column) depend on nothing the chain computes: they are
+// requested before the GEMM whose output the epilogue consumes and stay raw until then (see stage_load).
+template <int QM>
+__device__ __forceinline__ void epilogue_fwd_prefetch(const sca_mid_args& a, const sca_mid_layer& L, int r0,
+                                                      float (&vb)[QM][4], float (&vc)[QM][4]) {
+    const int row = threadIdx.x >> 3, t8 = threadIdx.x & 7;
+    const int N = L.N;
+    const int b = r0 + row;
+    // absent terms read g_mid_blank and are dropped by the epilogue
+    const int c = L.Wc ? a.cond[min(b, a.B - 1)] : 0;
+#pragma unroll
+    for (int q = 0; q < QM; ++q)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int hc = min(32 * q + 4 * t8 + u, N - 1);
+            const float* pb = L.bias ? L.bias + hc : g_mid_blank;
+            const float* pc = L.Wc ? L.Wc + (long long)hc * a.C + c : g_mid_blank;
+            vb[q][u] = *pb;
+            vc[q][u] = *pc;
+        }
+}
+
 template <int QM>
 __device__ __forceinline__ void layer_epilogue_fwd(const sca_mid_args& a, const sca_mid_layer& L, const float* pre,
-                                                   float* nxt, int ld, int r0) {
+                                                   float* nxt, int ld, int r0, const float (&vb)[QM][4],
+                                                   const float (&vc)[QM][4]) {
     const int row = threadIdx.x >> 3, t8 = threadIdx.x & 7;
     const int N = L.N, Npad = ((N + KC - 1) / KC) * KC;
     const int b = r0 + row;
     const bool live = b < a.B;
-    const int c = (live && L.Wc) ? a.cond[b] : 0;
     const bool vec = (N & 3) == 0 && ((((uintptr_t)L.yn | (uintptr_t)L.h) & 15) == 0);
     const float* prow = pre + row * ld;
     float v[QM][4];
@@ -235,12 +325,8 @@ __device__ __forceinline__ void layer_epilogue_fwd(const sca_mid_args& a, const 
     for (int q = 0; q < QM; ++q)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int hh = 32 * q + 4 * t8 + u;
-            float add = 0.f;
-            if (hh < N && live) {
-                if (L.bias) add = L.bias[hh];
-                if (L.Wc) add += L.Wc[(long long)hh * a.C + c];
-            }
+            float add = L.bias ? vb[q][u] : 0.f;
+            if (L.Wc) add += vc[q][u];
             v[q][u] = add;
         }
     float sum = 0.f;
@@ -309,6 +395,18 @@ __device__ __forceinline__ void layer_epilogue_fwd(const sca_mid_args& a, const 
     __syncthreads();
 }
 
+// The argument block is ~1 KB (17 cache lines) and the chain reads it piecemeal, phase by phase: every first touch of a
+// line is a scalar-cache miss that the single wave per SIMD waits out.  One burst of scalar loads up front - one
+// per line, all in flight together - brings the block into the scalar cache before the chain starts.
+__device__ __forceinline__ void warm_kernargs() {
+    const uint32_t __attribute__((address_space(4)))* kp =
+        (const uint32_t __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < (int)((sizeof(sca_mid_args) + 63) / 64); ++i) acc |= kp[16 * i];
+    asm volatile("" ::"s"(acc));
+}
+
 template <int NS>
 __global__ __launch_bounds__(256) void mid_fwd_kernel(const sca_mid_args a, int ld) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -318,86 +416,134 @@ __global__ __launch_bounds__(256) void mid_fwd_kernel(const sca_mid_args a, int 
     const int r0 = blockIdx.x * TM;
     float* cur = A0;
     float* oth = A1;
-    if (a.fuse_first) {
-        // first encoder layer: sum of the GEMM's split-K slabs -> bias / condition column / LayerNorm / ReLU / dropout
-        load_tile(oth, ld, a.pre0, a.S0, a.pre0_stride, r0, a.B, a.K0, a.K0);
-        __syncthreads();
-        layer_epilogue_fwd<2 * NS>(a, a.first, oth, cur, ld, r0);
-    } else {
-        // input tile (zero padded to a multiple of KC columns)
-        load_tile(A0, ld, a.h_in, 1, 0, r0, a.B, a.K0, ((a.K0 + KC - 1) / KC) * KC);
-    }
-    DBG(0);
-    for (int l = 0; l < a.n_enc; ++l) {
-        const sca_mid_layer& L = a.enc[l];
-        tile_gemm<true>(cur, ld, L.K, L.W, L.K, L.N, oth, ld, Ms);
-        DBG(1);
-        layer_epilogue_fwd<2 * NS>(a, L, oth, cur, ld, r0);
-        DBG(2);
-    }
-    // heads + reparameterised sample + KL
+    warm_kernargs();
+    DBG(15);
+    // ONE loop walks the chain - first-layer epilogue (g = -1), encoder layers, heads + latent block (g = n_enc), decoder
+    // layers - so the GEMM and the row epilogue exist once in the code: a straight-line chain is ~100 KB of
+    // instructions that every workgroup executes exactly once, more than the 64 KB instruction cache.
+    // It is also a software pipeline: the first weight chunk of the NEXT GEMM and the additive terms of the current
+    // epilogue are in flight while the current GEMM / epilogue run (one call site per prefetch, operands selected: a
+    // prefetch inside a branch has no fixed load count either).
     const int Z = a.Z;
-    tile_gemm<true>(cur, ld, a.Kh, a.Wh, a.Kh, 2 * Z, oth, ld, Ms);
-    DBG(3);
+    const int ng = a.n_enc + 1 + a.n_dec;
+    float wpre[NST], epb[2 * NS][4], epc[2 * NS][4];
+    auto gemm_ref = [&](int g, const float*& W, int& I, int& J) {     // operands of GEMM g (FWD: ldW = I)
+        if (g == a.n_enc) { W = a.Wh; I = a.Kh; J = 2 * Z; return; }
+        const sca_mid_layer& L = g < a.n_enc ? a.enc[g] : a.dec[g - a.n_enc - 1];
+        W = L.W; I = L.K; J = L.N;
+    };
     {
-        const int Zp = ((Z + KC - 1) / KC) * KC;
-        const uint32_t stp = a.step ? a.step[0] : 0u;
-        for (int t = threadIdx.x; t < TM * (Zp - Z); t += 256) {          // zero padding of the z tile
-            const int r = t / (Zp - Z), k = Z + t - r * (Zp - Z);
-            cur[r * ld + k] = 0.f;
-        }
-        for (int t = threadIdx.x; t < TM * Z; t += 256) {
-            const int r = t / Z, k = t - r * Z, b = r0 + r;
-            float zv = 0.f, kl = 0.f;
-            if (b < a.B) {
-                const float mu = oth[r * ld + k] + a.bh[k], lv = oth[r * ld + Z + k] + a.bh[Z + k];
-                const float var = expf(lv) + 1e-4f, sd = sqrtf(var);
-                float e = 0.f;
-                if (a.sample) {
-                    if (a.eps_in) {
-                        e = a.eps_in[(long long)b * Z + k];
-                    } else {
-                        float n0, n1;
-                        philox_normal2(a.seed + stp, a.rng_latent, (uint32_t)(b * ((Z + 1) / 2) + (k >> 1)), n0, n1);
-                        e = (k & 1) ? n1 : n0;
-                    }
-                }
-                const float vr = sd * sd;
-                kl = 0.5f * (vr + mu * mu - 1.0f - logf(vr));
-                a.mu_lv[(long long)b * 2 * Z + k] = mu;
-                a.mu_lv[(long long)b * 2 * Z + Z + k] = lv;
-                a.eps_out[(long long)b * Z + k] = e;
-                zv = fmaf(e, sd, mu);
-                a.z[(long long)b * Z + k] = zv;
-            }
-            cur[r * ld + k] = zv;
-            oth[r * ld + 2 * Z + k] = kl;                 // parked next to the head outputs, summed below
-        }
-        __syncthreads();
-        for (int r = threadIdx.x; r < TM; r += 256)
-            if (r0 + r < a.B) {
-                float t = 0.f;
-                for (int k = 0; k < Z; ++k) t += oth[r * ld + 2 * Z + k];
-                a.kl_row[r0 + r] = t;
-            }
-        __syncthreads();
+        const float* W; int I, J;
+        gemm_ref(0, W, I, J);
+        tile_gemm_prefetch<true>(wpre, W, I, I, J);
     }
-    DBG(4);
-    for (int l = 0; l < a.n_dec; ++l) {
-        const sca_mid_layer& L = a.dec[l];
-        tile_gemm<true>(cur, ld, L.K, L.W, L.K, L.N, oth, ld, Ms);
-        DBG(5 + 2 * l);
-        layer_epilogue_fwd<2 * NS>(a, L, oth, cur, ld, r0);
-        DBG(6 + 2 * l);
+    if (!a.fuse_first)        // input tile (zero padded to a multiple of KC columns)
+        load_tile(A0, ld, a.h_in, 1, 0, r0, a.B, a.K0, ((a.K0 + KC - 1) / KC) * KC);
+    DBG(0);
+    for (int g = a.fuse_first ? -1 : 0; g < ng; ++g) {
+        const bool head = g == a.n_enc, first = g < 0;
+        // the layer whose epilogue follows (heads: none - `first` stands in for the prefetch, which tolerates a blank layer)
+        const sca_mid_layer& L = (first || head) ? a.first : (g < a.n_enc ? a.enc[g] : a.dec[g - a.n_enc - 1]);
+        epilogue_fwd_prefetch<2 * NS>(a, L, r0, epb, epc);
+        if (first) {
+            // first encoder layer: sum of the GEMM's split-K slabs (its epilogue below)
+            load_tile(oth, ld, a.pre0, a.S0, a.pre0_stride, r0, a.B, a.K0, a.K0);
+            __syncthreads();
+        } else {
+            const float* W; int I, J;
+            gemm_ref(g, W, I, J);
+            tile_gemm<true>(cur, ld, I, W, I, J, oth, ld, Ms, wpre);
+        }
+        {
+            const float* W; int I, J;
+            gemm_ref(min(g + 1, ng - 1), W, I, J);           // (after the last GEMM: a harmless re-read)
+            tile_gemm_prefetch<true>(wpre, W, I, I, J);
+        }
+        DBG(1 + 2 * (g + 1));
+        if (!head) {
+            layer_epilogue_fwd<2 * NS>(a, L, oth, cur, ld, r0, epb, epc);
+        } else {
+            // heads -> reparameterised sample + KL
+            const int Zp = ((Z + KC - 1) / KC) * KC;
+            const uint32_t stp = a.step ? a.step[0] : 0u;
+            for (int t = threadIdx.x; t < TM * (Zp - Z); t += 256) {          // zero padding of the z tile
+                const int r = t / (Zp - Z), k = Z + t - r * (Zp - Z);
+                cur[r * ld + k] = 0.f;
+            }
+            for (int t = threadIdx.x; t < TM * Z; t += 256) {
+                const int r = t / Z, k = t - r * Z, b = r0 + r;
+                float zv = 0.f, kl = 0.f;
+                if (b < a.B) {
+                    const float mu = oth[r * ld + k] + a.bh[k], lv = oth[r * ld + Z + k] + a.bh[Z + k];
+                    const float var = expf(lv) + 1e-4f, sd = sqrtf(var);
+                    float e = 0.f;
+                    if (a.sample) {
+                        if (a.eps_in) {
+                            e = a.eps_in[(long long)b * Z + k];
+                        } else {
+                            float n0, n1;
+                            philox_normal2(a.seed + stp, a.rng_latent, (uint32_t)(b * ((Z + 1) / 2) + (k >> 1)), n0, n1);
+                            e = (k & 1) ? n1 : n0;
+                        }
+                    }
+                    const float vr = sd * sd;
+                    kl = 0.5f * (vr + mu * mu - 1.0f - logf(vr));
+                    a.mu_lv[(long long)b * 2 * Z + k] = mu;
+                    a.mu_lv[(long long)b * 2 * Z + Z + k] = lv;
+                    a.eps_out[(long long)b * Z + k] = e;
+                    zv = fmaf(e, sd, mu);
+                    a.z[(long long)b * Z + k] = zv;
+                }
+                cur[r * ld + k] = zv;
+                oth[r * ld + 2 * Z + k] = kl;                 // parked next to the head outputs, summed below
+            }
+            __syncthreads();
+            for (int r = threadIdx.x; r < TM; r += 256)
+                if (r0 + r < a.B) {
+                    float t = 0.f;
+                    for (int k = 0; k < Z; ++k) t += oth[r * ld + 2 * Z + k];
+                    a.kl_row[r0 + r] = t;
+                }
+            __syncthreads();
+        }
+        DBG(2 + 2 * (g + 1));
     }
 }
 
 // Row epilogue of one layer (backward): upstream gradient tile `g` -> dropout / ReLU / LayerNorm backward -> da
 // (HBM + tile `dst`, zero padded).  Same thread layout as the forward epilogue; the saved normalised pre-activations
 // are fetched from HBM up front.
+// The saved normalised pre-activations (and rstd) an epilogue needs are requested one GEMM ahead.
+template <int QM>
+__device__ __forceinline__ void epilogue_bwd_prefetch(const sca_mid_args& a, const sca_mid_layer& L, bool none, int r0,
+                                                      float (&y)[QM][4], float& rsv) {
+    const int row = threadIdx.x >> 3, t8 = threadIdx.x & 7;
+    const int N = L.N;
+    const int b = r0 + row;
+    const bool live = b < a.B;
+    const bool vec = (N & 3) == 0 && ((((uintptr_t)L.yn | (uintptr_t)L.da) & 15) == 0);
+    // unconditional loads from clamped addresses (see stage_load); `none` (no epilogue follows) reads g_mid_blank
+    const long long bc = min(b, a.B - 1);
+    const bool have = !none && L.yn;
+    const float* yb = have ? L.yn + bc * N : g_mid_blank;
+#pragma unroll
+    for (int q = 0; q < QM; ++q) {
+        const int h4 = 32 * q + 4 * t8;
+        if (vec) {
+            const float4 t = *reinterpret_cast<const float4*>(yb + (have ? min(h4, N - 4) : 0));
+            y[q][0] = t.x; y[q][1] = t.y; y[q][2] = t.z; y[q][3] = t.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) y[q][u] = yb[have ? min(h4 + u, N - 1) : 0];
+        }
+    }
+    const bool has_rs = a.norm == 1 && !none && L.rs;
+    rsv = *(has_rs ? L.rs + bc : g_mid_blank);
+}
+
 template <int QM>
 __device__ __forceinline__ void layer_epilogue_bwd(const sca_mid_args& a, const sca_mid_layer& L, const float* g,
-                                                   float* dst, int ld, int r0) {
+                                                   float* dst, int ld, int r0, const float (&y)[QM][4], float rsv) {
     const int row = threadIdx.x >> 3, t8 = threadIdx.x & 7;
     const int N = L.N, Npad = ((N + KC - 1) / KC) * KC;
     const int b = r0 + row;
@@ -407,21 +553,7 @@ __device__ __forceinline__ void layer_epilogue_bwd(const sca_mid_args& a, const 
     const uint32_t stp = a.step ? a.step[0] : 0u;
     const float* grow = g + row * ld;
     float* drow = dst + row * ld;
-    float x[QM][4], y[QM][4];
-#pragma unroll
-    for (int q = 0; q < QM; ++q) {
-        const int h4 = 32 * q + 4 * t8;
-        const long long o = (long long)b * N + h4;
-        if (vec) {
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (h4 < N && live) t = *reinterpret_cast<const float4*>(L.yn + o);
-            y[q][0] = t.x; y[q][1] = t.y; y[q][2] = t.z; y[q][3] = t.w;
-        } else {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) y[q][u] = (h4 + u < N && live) ? L.yn[o + u] : 0.f;
-        }
-    }
-    const float rsv = (a.norm == 1 && live) ? L.rs[b] : 0.f;
+    float x[QM][4];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int q = 0; q < QM; ++q) {
@@ -484,6 +616,29 @@ __global__ __launch_bounds__(256) void mid_bwd_kernel(const sca_mid_args a, int 
     float* Ms = A1 + TM * ld;
     const int r0 = blockIdx.x * TM;
     const int Z = a.Z;
+    warm_kernargs();
+    // One loop walks the chain backwards (decoder layers, latent block + heads at g = n_enc, encoder layers, first-layer
+    // epilogue at g = -1): one instance of the GEMM and of the epilogue, weights of the NEXT GEMM and the saved
+    // activations of the NEXT epilogue requested one phase ahead - see mid_fwd_kernel.
+    const int ng = a.n_enc + 1 + a.n_dec;
+    const int gmin = a.fuse_first ? -1 : 0;
+    float wpre[NST], ypre[2 * NS][4], rspre = 0.f;
+    // layer of chain position g (g != n_enc; only references into the kernel arguments: a local stand-in would push
+    // the whole argument block through private memory)
+#define MID_LAYER(g) ((g) < 0 ? a.first : ((g) < a.n_enc ? a.enc[(g)] : a.dec[(g) - a.n_enc - 1]))
+    auto gemm_ref = [&](int g, const float*& W, int& ldW, int& I, int& J) {   // dX = dA W: I = outputs, J = inputs
+        if (g == a.n_enc) { W = a.Wh; ldW = a.Kh; I = 2 * Z; J = a.Kh; return; }
+        const sca_mid_layer& L = g < a.n_enc ? a.enc[g] : a.dec[g - a.n_enc - 1];
+        W = L.W; ldW = L.K; I = L.N; J = L.K;
+    };
+    {
+        const float* W; int ldW, I, J;
+        gemm_ref(ng - 1, W, ldW, I, J);
+        tile_gemm_prefetch<false>(wpre, W, ldW, I, J);
+        const bool none = ng - 1 == a.n_enc;                 // (the heads have no epilogue)
+        const sca_mid_layer& L = none ? a.first : a.dec[a.n_dec - 1];
+        epilogue_bwd_prefetch<2 * NS>(a, L, none, r0, ypre, rspre);
+    }
     // upstream gradient tile: sum of the dX slabs of the output GEMM
     {
         const int N = a.n_dec ? a.dec[a.n_dec - 1].N : Z;
@@ -492,46 +647,54 @@ __global__ __launch_bounds__(256) void mid_bwd_kernel(const sca_mid_args a, int 
     }
     float* cur = A0;
     float* oth = A1;
-    for (int l = a.n_dec - 1; l >= 0; --l) {
-        const sca_mid_layer& L = a.dec[l];
-        layer_epilogue_bwd<2 * NS>(a, L, cur, oth, ld, r0);               // oth = da [TM][N]
-        tile_gemm<false>(oth, ld, L.N, L.W, L.K, L.K, cur, ld, Ms);       // cur = dX [TM][K]
-    }
-    // latent block: dz (+ dz2) + KL -> d[mean | log_var]
-    {
-        const float akl = a.hyper[0] / (float)a.B;
-        const int Hp = ((2 * Z + KC - 1) / KC) * KC;
-        for (int t = threadIdx.x; t < TM * (Hp - 2 * Z); t += 256) {      // zero padding of the d-heads tile
-            const int r = t / (Hp - 2 * Z), k = 2 * Z + t - r * (Hp - 2 * Z);
-            oth[r * ld + k] = 0.f;
-        }
-        for (int t = threadIdx.x; t < TM * 2 * Z; t += 256) {
-            const int r = t / (2 * Z), k = t - r * 2 * Z, b = r0 + r;
-            float o = 0.f;
-            if (b < a.B) {
-                const int kk = k < Z ? k : k - Z;
-                float g = cur[r * ld + kk];
-                if (a.dz2) g += a.dz2[(long long)b * Z + kk];
-                const float mu = a.mu_lv[(long long)b * 2 * Z + kk], lv = a.mu_lv[(long long)b * 2 * Z + Z + kk];
-                const float ev = expf(lv), var = ev + 1e-4f, sd = sqrtf(var);
-                o = k < Z ? g + akl * mu
-                          : g * a.eps_out[(long long)b * Z + kk] * (0.5f * ev / sd) + akl * 0.5f * (1.0f - 1.0f / var) * ev;
-                a.dheads[(long long)b * 2 * Z + k] = o;
+    for (int g = ng - 1; g >= gmin; --g) {
+        const bool head = g == a.n_enc;
+        if (!head) {
+            const sca_mid_layer& L = MID_LAYER(g);
+            layer_epilogue_bwd<2 * NS>(a, L, cur, oth, ld, r0, ypre, rspre);                // oth = da [TM][N]
+        } else {
+            // latent block: dz (+ dz2) + KL -> d[mean | log_var]
+            const float akl = a.hyper[0] / (float)a.B;
+            const int Hp = ((2 * Z + KC - 1) / KC) * KC;
+            for (int t = threadIdx.x; t < TM * (Hp - 2 * Z); t += 256) {      // zero padding of the d-heads tile
+                const int r = t / (Hp - 2 * Z), k = 2 * Z + t - r * (Hp - 2 * Z);
+                oth[r * ld + k] = 0.f;
             }
-            oth[r * ld + k] = o;
+            for (int t = threadIdx.x; t < TM * 2 * Z; t += 256) {
+                const int r = t / (2 * Z), k = t - r * 2 * Z, b = r0 + r;
+                float o = 0.f;
+                if (b < a.B) {
+                    const int kk = k < Z ? k : k - Z;
+                    float gz = cur[r * ld + kk];
+                    if (a.dz2) gz += a.dz2[(long long)b * Z + kk];
+                    const float mu = a.mu_lv[(long long)b * 2 * Z + kk], lv = a.mu_lv[(long long)b * 2 * Z + Z + kk];
+                    const float ev = expf(lv), var = ev + 1e-4f, sd = sqrtf(var);
+                    o = k < Z ? gz + akl * mu
+                              : gz * a.eps_out[(long long)b * Z + kk] * (0.5f * ev / sd) + akl * 0.5f * (1.0f - 1.0f / var) * ev;
+                    a.dheads[(long long)b * 2 * Z + k] = o;
+                }
+                oth[r * ld + k] = o;
+            }
+            // tile_gemm starts with a barrier
         }
-        // tile_gemm starts with a barrier
-        tile_gemm<false>(oth, ld, 2 * Z, a.Wh, a.Kh, a.Kh, cur, ld, Ms);  // cur = d h_enc_last [TM][Kh]
+        if (g < 0) return;               // first encoder layer backward done: `oth` / da0 feed its dW GEMM
+        // saved activations of the next epilogue (g - 1; none after the last GEMM or before the latent block)
+        {
+            const int gn = g - 1;
+            const bool none = gn < gmin || gn == a.n_enc;
+            const int gs = none ? -1 : gn;
+            const sca_mid_layer& Ln = MID_LAYER(gs);
+            epilogue_bwd_prefetch<2 * NS>(a, Ln, none, r0, ypre, rspre);
+        }
+        {
+            const float* W; int ldW, I, J;
+            gemm_ref(g, W, ldW, I, J);
+            tile_gemm<false>(oth, ld, I, W, ldW, J, cur, ld, Ms, wpre);       // cur = dX [TM][K]
+            gemm_ref(max(g - 1, 0), W, ldW, I, J);                            // (after the last GEMM: a harmless re-read)
+            tile_gemm_prefetch<false>(wpre, W, ldW, I, J);
+        }
     }
-    for (int l = a.n_enc - 1; l >= 0; --l) {
-        const sca_mid_layer& L = a.enc[l];
-        layer_epilogue_bwd<2 * NS>(a, L, cur, oth, ld, r0);
-        tile_gemm<false>(oth, ld, L.N, L.W, L.K, L.K, cur, ld, Ms);
-    }
-    if (a.fuse_first) {                  // first encoder layer backward: `cur` = d h0 -> da0 (its dW GEMM reads it)
-        layer_epilogue_bwd<2 * NS>(a, a.first, cur, oth, ld, r0);
-        return;
-    }
+#undef MID_LAYER
     if ((a.K0 & 3) == 0 && ((uintptr_t)a.dh_out & 15) == 0) {
         const int w4 = a.K0 >> 2;
         for (int t = threadIdx.x; t < TM * w4; t += 256) {

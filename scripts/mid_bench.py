@@ -17,9 +17,15 @@ def phases(L, rf, st, tag):
     L.sca_mid_fwd(rf, st); torch.cuda.synchronize()
     fn(buf)
     t = [buf[i] for i in range(16)]
-    names = ["first-layer epilogue", "enc1 gemm", "enc1 epilogue", "heads gemm", "latent", "dec0 gemm", "dec0 epilogue",
-             "dec1 gemm", "dec1 epilogue"]
-    marks = [t[15], t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8]]
+    # marks of mid_fwd_kernel (SCA_MID_DEBUG build, H = [128, 128]): 15 start, 0 first prefetch / input tile, then two per
+    # chain position (after the GEMM or slab load, after the epilogue / latent block)
+    names = ["prefetch", "first slabs", "first epilogue", "enc1 gemm", "enc1 epilogue", "heads gemm", "latent",
+             "dec0 gemm", "dec0 epilogue", "dec1 gemm", "dec1 epilogue"]
+    marks = [t[15]] + t[0:11]
+    tt = [buf[i] for i in range(64)]
+    mhz = (tt[32 + 10] - tt[32 + 15]) / max(1, (tt[10] - tt[15])) * 100.0
+    print(tag, "shader clock MHz over the kernel:", round(mhz), "| last gemm, first chunk (us): entry->barrier..store..barrier..load issue..mfma done",
+          [round((tt[i + 1] - tt[i]) / 100.0, 2) for i in range(16, 20)], flush=True)
     print(tag, "fwd phases (us):", {n: round((marks[i + 1] - marks[i]) / 100.0, 2) for i, n in enumerate(names)},
           "total", round((marks[-1] - marks[0]) / 100.0, 2), flush=True)
 
@@ -40,8 +46,8 @@ for B in (128, 4096, 16384):
         torch.cuda.synchronize()
         st = torch.cuda.current_stream().cuda_stream
         L = _lib.load()
-        (af, rf), = [v for k, v in eng._mid_cache.items() if k[6] is None]
-        (ab, rb), = [v for k, v in eng._mid_cache.items() if k[6] is not None]
+        (af, rf), = [v for k, v in eng._mid_cache.items() if k[7] is None]
+        (ab, rb), = [v for k, v in eng._mid_cache.items() if k[7] is not None]
         for name, fn, ref in (("fwd", L.sca_mid_fwd, rf), ("bwd", L.sca_mid_bwd, rb)):
             for _ in range(3):
                 fn(ref, st)

@@ -170,10 +170,11 @@ def test_mmd_golden(lib, key):
         assert rel_err(grad, z[f"mmd_{key}_grad"]) < 5e-5
 
 
-@pytest.fixture
-def mfma_form(lib):
-    """The MFMA form of the row-block MMD kernel (opt-in tuning hook), restored afterwards."""
-    prev = lib.sca_mmd_select_form(1)
+@pytest.fixture(params=[1, 2], ids=["rows-mfma", "symmetric-mfma"])
+def mfma_form(lib, request):
+    """The MFMA forms of the MMD kernels (1: row-block kernel, 2: symmetric whole-minibatch kernel; process-wide tuning
+    hook), restored afterwards."""
+    prev = lib.sca_mmd_select_form(request.param)
     yield
     torch.cuda.synchronize()
     lib.sca_mmd_select_form(prev)
@@ -186,7 +187,7 @@ def test_mmd_golden_mfma_form(lib, key, mfma_form):
     test_mmd_golden(lib, key)
 
 
-@pytest.mark.parametrize("B,D,C", [(1500, 10, 7), (4096, 10, 20), (777, 6, 3)])
+@pytest.mark.parametrize("B,D,C", [(1500, 10, 7), (4096, 10, 20), (777, 6, 3), (128, 10, 2), (200, 4, 5)])
 def test_mmd_mfma_form_far_tiles_vs_fp64(lib, mfma_form, B, D, C):
     """Sizes at which most 16 x 16 tiles are far (d2 >= 2 everywhere: distances from the augmented-vector MFMA, owner
     gradients from the accumulator-as-operand MFMA) against a plain fp64 evaluation of the reference's formula
