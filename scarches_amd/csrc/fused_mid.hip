@@ -227,8 +227,8 @@ __device__ __forceinline__ float row8_sum(float v) {      // sum over the 8 cons
 __device__ __forceinline__ void load_tile(float* __restrict__ dst, int ld, const float* __restrict__ src, int S,
                                           long long stride, int r0, int B, int width, int Kp) {
     if ((width & 3) == 0 && ((uintptr_t)src & 15) == 0 && (stride & 3) == 0) {
-        // NP positions of a thread x two slabs = 8 independent 16-byte loads in flight (a serial position / slab walk pays
-        // one HBM latency per load: 11 us for the four slabs of the first layer at B = 8192)
+        // NP positions of a thread x four slabs = 16 independent 16-byte loads in flight (a serial position / slab walk
+        // pays one HBM latency per load: 11 us for the slabs of the first layer at B = 8192)
         constexpr int NP = 4;
         const int w4 = Kp >> 2;
         for (int t0 = threadIdx.x; t0 < TM * w4; t0 += 256 * NP) {
@@ -244,26 +244,20 @@ __device__ __forceinline__ void load_tile(float* __restrict__ dst, int ld, const
                 off[i] = t < TM * w4 ? r * ld + k : -1;
                 v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            int q = 0;
-            for (; q + 1 < S; q += 2) {
-                float4 u[NP][2];
+            // slabs in groups of four (16 loads in flight), summed in slab order
+            for (int q = 0; q < S; q += 4) {
+                float4 u[NP][4];
 #pragma unroll
                 for (int i = 0; i < NP; ++i)
 #pragma unroll
-                    for (int h = 0; h < 2; ++h)
-                        u[i][h] = p[i] ? *reinterpret_cast<const float4*>(p[i] + (q + h) * stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int h = 0; h < 4; ++h)
+                        u[i][h] = (p[i] && q + h < S) ? *reinterpret_cast<const float4*>(p[i] + (q + h) * stride)
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int i = 0; i < NP; ++i)
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) { v[i].x += u[i][h].x; v[i].y += u[i][h].y; v[i].z += u[i][h].z; v[i].w += u[i][h].w; }
-            }
-            if (q < S) {
-                float4 u[NP];
-#pragma unroll
-                for (int i = 0; i < NP; ++i)
-                    u[i] = p[i] ? *reinterpret_cast<const float4*>(p[i] + q * stride) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int i = 0; i < NP; ++i) { v[i].x += u[i].x; v[i].y += u[i].y; v[i].z += u[i].z; v[i].w += u[i].w; }
+                    for (int h = 0; h < 4; ++h)
+                        if (q + h < S) { v[i].x += u[i][h].x; v[i].y += u[i][h].y; v[i].z += u[i][h].z; v[i].w += u[i][h].w; }
             }
 #pragma unroll
             for (int i = 0; i < NP; ++i)
