@@ -173,15 +173,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int tile, int zs, f
     float* Bs = lds + NSTAGE * ASZ;
     const int aoff = half * LDA + wm * (32 * WM) + l31, boff = half * LDB + wn * (32 * WN) + l31;
     float av[2][BK / 2][WM], bv[2][BK / 2][WN];
+    // prologue: tiles 0 and 1 are requested together (ONE exposed memory latency, not two - a short-K GEMM such as the
+    // output layer, K = 128, spends more time here than in its eight k-steps)
     if (nk > 0) {
         load_tile<AMODE, VEC, WM>(a.A, a.lda, a.M, m0, kbeg, kend, ra[0]);
         load_tile<BMODE, VEC, WN>(a.B, a.ldb, a.N, n0, kbeg, kend, rb[0]);
-        store_tile<AMODE, WM>(As, ra[0]);
-        store_tile<BMODE, WN>(Bs, rb[0]);
     }
     if (nk > 1) {
         load_tile<AMODE, VEC, WM>(a.A, a.lda, a.M, m0, kbeg + BK, kend, ra[1]);
         load_tile<BMODE, VEC, WN>(a.B, a.ldb, a.N, n0, kbeg + BK, kend, rb[1]);
+    }
+    if (nk > 0) {
+        store_tile<AMODE, WM>(As, ra[0]);
+        store_tile<BMODE, WN>(Bs, rb[0]);
+    }
+    if (nk > 1) {
         store_tile<AMODE, WM>(As + ASZ, ra[1]);
         store_tile<BMODE, WN>(Bs + BSZ, rb[1]);
     }
@@ -272,6 +278,34 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, int tile, int zs, f
 
     float* C = a.C + (long long)zs * a.slab_stride;
     const bool add_bias = a.bias != nullptr && a.nsplit == 1;
+    if constexpr (WM == 1 && WN == 1) {
+        // 64 x 64 tiles leave through LDS: the accumulator layout gives every lane ONE column (4-byte stores, two
+        // 128-byte row pieces per wave instruction); staged row-major, a thread stores 16 bytes and a wave instruction
+        // four complete 256-byte row segments.  (The k loop ended with a barrier: the operand stages are free.)
+        if ((a.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0 && (a.N & 3) == 0 && (a.slab_stride & 3) == 0) {
+            constexpr int LDC = 64 + 4;
+            float* Ct = lds;                   // 64 x 68 floats = 17 KB of the 26 KB operand ring
+            const int nc = wn * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Ct[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + nc] = acc[0][0][r];
+            const int c4 = 4 * (threadIdx.x & 15), rr = threadIdx.x >> 4;
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (add_bias && n0 + c4 < a.N) b4 = *reinterpret_cast<const float4*>(a.bias + n0 + c4);
+            __syncthreads();
+            if (n0 + c4 < a.N) {
+#pragma unroll
+                for (int pass = 0; pass < 4; ++pass) {
+                    const int row = rr + 16 * pass, m = m0 + row;
+                    if (m < a.M) {
+                        float4 v = *reinterpret_cast<const float4*>(&Ct[row * LDC + c4]);
+                        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                        *reinterpret_cast<float4*>(C + (long long)m * a.ldc + n0 + c4) = v;
+                    }
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < WM; ++i)
 #pragma unroll

@@ -83,6 +83,26 @@ def test_slab_reduce_many_slabs(lib, S, n):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize("M,N,K", [(6200, 2000, 128), (1000, 132, 64), (333, 2000, 100), (64, 128, 12)])
+def test_gemm_short_k_row_major_epilogue(lib, M, N, K):
+    """Forward GEMMs with a short contraction (the output layer): 64 x 64 tiles leave through LDS as 16-byte row-major
+    stores when the output allows it (N % 4 == 0) - against fp64, with and without bias, ragged rows / columns."""
+    from scarches_amd import _lib
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g), torch.randn(N, generator=g)
+    Ad, Wd, bd = dev(A), dev(W), dev(b)
+    ref = A.double() @ W.double().t()
+    scale = (A.abs().double() @ W.abs().double().t()).max().item()
+    for bias in (None, bd):
+        out = torch.full((M, N), float("nan"), device="cuda")
+        _lib.check(lib.sca_gemm_f32_cfg(0, 0, Ad.data_ptr(), K, Wd.data_ptr(), K, out.data_ptr(), N, M, N, K, 1, 0,
+                                        bias.data_ptr() if bias is not None else None, 1, 1, st()), "gemm")
+        torch.cuda.synchronize()
+        r = ref + (b.double() if bias is not None else 0.0)
+        err = (out.cpu().double() - r).abs().max().item()
+        assert err <= 2e-6 * scale, (err, scale)
+
+
 def test_gemm_bias_and_unaligned(lib):
     from scarches_amd import _lib
     M, N, K = 33, 50, 19           # lda/ldb not multiples of 4 -> scalar staging path
