@@ -110,6 +110,22 @@ __device__ __forceinline__ bool nb_gamma_fast_ok(float x, float th) {
     return x <= 16.0f && x == floorf(x) && th < 128.0f && th > 1e-30f;
 }
 
+// All loads of a register array issued before any of them is consumed: ONE asm statement names every element, so
+// each load sits ahead of it in program order and the values are first touched behind it.  (hipcc turns
+// `v = in_range ? p[i] : x` into a branch per element with the load and its wait inside - EPT serial memory latencies
+// per row, which was most of this kernel's time - and sinks an unconditional load that feeds a select back into one.)
+template <int N>
+__device__ __forceinline__ void loads_in_flight(float (&v)[N]) {
+    static_assert(N == 4 || N == 8 || N == 12, "instantiated element counts");
+    if constexpr (N == 4)
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+    else if constexpr (N == 8)
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+    else
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                          "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]));
+}
+
 constexpr int QMAX = 1024;     // LDS queue of heavy entries per row (overflow is handled inline)
 
 template <int T, int EPT, bool ZINB>
@@ -168,10 +184,23 @@ __global__ __launch_bounds__(T, 4) void recon_rows_kernel(const ReconArgs a) {
         // ---- online softmax statistics: per-thread (max, sum exp), merged across the workgroup in one round
         float lg[EPT];
         float mx = -INFINITY;
+        // the whole row (and its per-condition offsets) requested at once from clamped addresses
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) lg[j] = lrow[min(t + T * j, G - 1)];
+        if (coff) {
+            float co[EPT];
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) co[j] = coff[min(t + T * j, G - 1)];
+            loads_in_flight(co);
+            loads_in_flight(lg);
+#pragma unroll
+            for (int j = 0; j < EPT; ++j) lg[j] += co[j];
+        } else {
+            loads_in_flight(lg);
+        }
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
-            const int g = t + T * j;
-            lg[j] = g < G ? lrow[g] + (coff ? coff[g] : 0.f) : -INFINITY;
+            if (t + T * j >= G) lg[j] = -INFINITY;
             mx = fmaxf(mx, lg[j]);
         }
         // the first stored count of this lane travels together with the logits (its two dependent reads overlap the
@@ -188,11 +217,19 @@ __global__ __launch_bounds__(T, 4) void recon_rows_kernel(const ReconArgs a) {
         if (c != ccur) {
             ccur = c;
 #pragma unroll
+            for (int j = 0; j < EPT; ++j) thr[j] = tth[min(t + T * j, G - 1)];
+            if (ZINB) {
+#pragma unroll
+                for (int j = 0; j < EPT; ++j) lter[j] = tlt[min(t + T * j, G - 1)];
+                loads_in_flight(lter);
+            }
+            loads_in_flight(thr);
+#pragma unroll
             for (int j = 0; j < EPT; ++j) {
-                const int g = t + T * j;
-                thr[j] = g < G ? tth[g] : 1.f;
+                const bool in = t + T * j < G;
+                if (!in) thr[j] = 1.f;
                 // ZINB keeps log(theta + eps); NB keeps 1 / (theta + eps) (its dense sweep needs no other table value)
-                if (ZINB) lter[j] = g < G ? tlt[g] : 0.f;
+                if (ZINB) { if (!in) lter[j] = 0.f; }
                 else lter[j] = __builtin_amdgcn_rcpf(thr[j] + NB_EPS);
             }
         }
