@@ -273,6 +273,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(warmup, warmup + steps):
             one(i)
+        run.host_issue_s = time.perf_counter() - t0     # host time to ENQUEUE the steps (the GPU runs behind it)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -284,6 +285,7 @@ def main():
         return dt
 
     dt = run(B, a.steps, a.warmup)
+    host_issue_ms = run.host_issue_s / a.steps * 1e3
     value = B * world * a.steps / dt
     losses = eng.losses.tolist()
     extra = {}
@@ -310,6 +312,7 @@ def main():
                    "mmd": "single device" if world == 1 else
                           ("global minibatch (all-gather of z)" if a.dp_mmd == "exact" else "per-rank slice")},
         "final_losses": {"recon": losses[0], "kl": losses[1], "mmd": losses[2]},
+        "host_issue_ms_per_step": host_issue_ms,
     }
     if extra:
         out["extra"] = extra

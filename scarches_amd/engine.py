@@ -607,7 +607,7 @@ class CVAEEngine:
             self._rec.append((fn, args, False))
         return fn(*args)
 
-    def _defer(self, fn, lane=0, join=()):
+    def _defer(self, fn, lane=0, join=(), reuse=False):
         """Side work for an aux stream (lane 0: self.aux, lane 1: self.aux2) that depends on everything enqueued on
         the main stream so far.  The dependency point (an event) is taken now, the launches are issued at the next
         _flush(): the host keeps feeding the critical main-stream chain first, the aux streams fill in behind it.
@@ -616,8 +616,13 @@ class CVAEEngine:
         if not self.overlap:
             fn(torch.cuda.current_stream(self.device).cuda_stream)
             return
-        ev = self._next_event()
-        self._call(ev.record, torch.cuda.current_stream(self.device))
+        if reuse and self._aux_q:
+            # same dependency point as the previous deferral (nothing was launched on the main stream in between):
+            # share its event - every event recorded between two kernels of the main chain costs ~6 us there
+            ev = self._aux_q[-1][0]
+        else:
+            ev = self._next_event()
+            self._call(ev.record, torch.cuda.current_stream(self.device))
         self._aux_q.append((ev, fn, lane, tuple(join)))
 
     def _lane_stream(self, lane):
@@ -1252,6 +1257,8 @@ class CVAEEngine:
         h_last = ws[self.dec[-1].tag + ".h"].data_ptr()
         self._gemm(0, 0, h_last, Hd, P[self.out_w].data_ptr(), Hd, B, G, Hd, st, out=ws["logits"].data_ptr(), ldc=G,
                    bias=P[self.out_b].data_ptr(), force_s1=True)
+        # (measured: with this wait moved in front of the output GEMM - to spare the stream operation between the GEMM
+        #  and the likelihood kernel - the GEMM is dispatched behind the MMD, which then holds every CU: 0.665 -> 0.753 ms)
         self._wait(self._ev_pro)
         rpb = _recon_rows_per_block(B)
         gob = self.g[self.out_b].data_ptr() if T[self.out_b] else None
@@ -1288,7 +1295,8 @@ class CVAEEngine:
             if self.has_theta and T["theta"]:
                 _lib.check(L.sca_transpose_scale(ws["dthetaT"].data_ptr(), max(C, 1), G, -1.0 / B,
                                                  Gd["theta"].data_ptr(), sa), "transpose_scale")
-        self._defer(recon_side, lane=1)         # own stream: starts right behind the likelihood kernel
+        # own stream: starts right behind the likelihood kernel (same dependency point as the loss finalisation)
+        self._defer(recon_side, lane=1, reuse=not mmd_split)
         if mmd_split:
             self._flush()                       # the second MMD block must be enqueued before mid_bwd can wait for it
         sp, S, stride = self._gemm(0, 1, dl, G, P[self.out_w].data_ptr(), Hd, B, Hd, G, st, max_split=self._mid_max_split)
@@ -1339,6 +1347,9 @@ class CVAEEngine:
         finally:
             jobs, self._gg_jobs = self._gg_jobs, None
         self._launch_group(jobs, st)
+        # (measured: gradient tail + Adam on the main stream instead, so that the next step queues behind Adam without
+        #  a cross-stream hop: 0.6640 -> 0.6626 ms, within noise - the ~15 us between Adam and the next step's first
+        #  kernel is dispatch latency, not the hop; the host enqueues a step in 0.39 ms and stays ahead)
         self._defer_tail(join=(1,))
         self._wait(self._flush())
         return self.losses
