@@ -6,9 +6,10 @@
 // (scarches/models/trvae/modules.py:52-97 Encoder, :124-208 Decoder, models/base/_base.py:391-407 sampling,
 // models/trvae/trvae.py:143-147 KL).  As separate GEMM + epilogue launches that chain is ~16 launches of a few us
 // each in both directions - launch- and latency-bound, a third of the step at B = 4096.  Here a workgroup owns a tile of
-// 32 cells and walks the whole chain with the activations in LDS: weights stream through LDS in 32-deep chunks, each
-// thread keeps a 4x4 register tile (fp32 FMA; the vector and matrix fp32 peaks of this part are equal), the row-wise
-// epilogues (bias, condition column, LayerNorm, ReLU, dropout; their backward) are the ones of layers.hip.
+// 16 cells and walks the whole chain with the activations in LDS: weights stream through LDS in 64-deep chunks, each
+// wave owns two 16 x 16 v_mfma_f32_16x16x4_f32 output blocks, the row-wise epilogues (bias, condition column, LayerNorm,
+// ReLU, dropout; their backward) are the ones of layers.hip.  (16 cells, not 32: the kernels are latency-bound chains,
+// and at 8192 cells per step 512 workgroups put two independent chains on every SIMD where 256 left one.)
 // Everything the backward pass and the weight-gradient GEMMs need (normalised pre-activations, rstd, activations,
 // mean / log-var, noise, z, per-layer `da`) is still written to HBM; only the re-reads and the launches disappear.
 #include "common.h"
@@ -76,7 +77,9 @@ namespace {
 
 __device__ __attribute__((aligned(16))) float g_mid_blank[4];   // what an unconditional prefetch reads for an absent operand
 
-constexpr int TM = 32;          // cells per workgroup
+constexpr int TM = 16;          // cells per workgroup
+constexpr int TPR = 256 / TM;   // threads per row in the row epilogues
+constexpr int CG = 4 * TPR;     // columns covered by one 4-column group per thread of a row
 constexpr int KC = 64;          // reduction chunk staged in LDS (64 deep: half as many exposed weight-fetch latencies)
 constexpr int MS_LD = 129;      // leading dim of the staged weight chunk [KC][128] (+1: conflict-free transposed store)
 constexpr int MAXW = 256;       // widest supported layer
@@ -132,11 +135,11 @@ __device__ __forceinline__ void stage_store(const float (&v)[NST], float* __rest
     }
 }
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// One v_mfma_f32_32x32x2_f32 output block per wave: wave w owns columns [32w, 32w+32) of the current 128-column block,
-// all TM = 32 rows.  Operand layout of the instruction: A lane (l31, half) = act[l31][k + half], B lane (l31, half) =
-// M(k + half, l31); accumulator register r of lane (l31, half) = out[(r & 3) + 8 (r >> 2) + 4 half][l31].
+// Two v_mfma_f32_16x16x4_f32 output blocks per wave: wave w owns columns [32w, 32w+32) of the current 128-column block
+// as two 16-column halves, all TM = 16 rows.  Operand layout of the instruction: A lane (l16, kg) = act[l16][k + kg],
+// B lane (l16, kg) = M(k + kg, l16); accumulator register r of lane (l16, kg) = out[4 kg + r][l16].
 // First weight chunk of a tile_gemm, requested early: the caller issues it BEFORE the row epilogue (or tile load) that
 // precedes the GEMM, so its L2 / HBM latency is hidden behind that phase instead of opening every GEMM.
 template <bool FWD>
@@ -149,57 +152,63 @@ __device__ __forceinline__ void tile_gemm(const float* __restrict__ act, int lda
                                           int ldW, int J, float* __restrict__ out, int ldo, float* __restrict__ Ms,
                                           float (&nxt)[NST]) {
     // `nxt` arrives holding chunk (i0 = 0, j0 = 0) - tile_gemm_prefetch - and is consumed
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31, half = lane >> 5;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l16 = lane & 15, kg = lane >> 4;
     for (int j0 = 0; j0 < J; j0 += 128) {
         const int jn = min(128, J - j0);
         const bool has_cols = 32 * w < jn;          // narrow outputs (heads: 2 Z columns) leave whole waves without work
-        f32x16 acc;
+        f32x4 acc[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[c][r] = 0.f;
         if (j0 > 0) stage_load<FWD>(nxt, W, ldW, 0, min(KC, I), j0, jn);
         for (int i0 = 0; i0 < I; i0 += KC) {
             __syncthreads();                         // previous chunk consumed (and `act` complete on first entry)
-            if (FWD && i0 == 0) DBG(16);
             stage_store<FWD>(nxt, Ms, min(KC, I - i0), jn);
-            if (FWD && i0 == 0) DBG(17);
             __syncthreads();
-            if (FWD && i0 == 0) DBG(18);
             if (i0 + KC < I) stage_load<FWD>(nxt, W, ldW, i0 + KC, min(KC, I - i0 - KC), j0, jn);
-            if (FWD && i0 == 0) DBG(19);
             if (!has_cols) continue;
-            const float* ap = act + l31 * lda + i0 + half;
-            const float* bp = Ms + half * MS_LD + 32 * w + l31;
-            const int kn = (min(KC, I - i0) + 1) >> 1;      // k pairs that hold data (z -> first decoder layer: 5 of 32)
-            if (kn == KC / 2) {
-                float av[KC / 2], bv[KC / 2];
+            const float* ap = act + l16 * lda + i0 + kg;
+            const float* bp = Ms + kg * MS_LD + 32 * w + l16;
+            const int kn = (min(KC, I - i0) + 3) >> 2;      // k quads that hold data (z -> first decoder layer: 3 of 16)
+            if (kn == KC / 4) {
+                float av[KC / 4], bv[KC / 4][2];
 #pragma unroll
-                for (int kk = 0; kk < KC / 2; ++kk) {
-                    av[kk] = ap[2 * kk];
-                    bv[kk] = bp[2 * kk * MS_LD];
+                for (int s = 0; s < KC / 4; ++s) {
+                    av[s] = ap[4 * s];
+                    bv[s][0] = bp[4 * s * MS_LD];
+                    bv[s][1] = bp[4 * s * MS_LD + 16];
                 }
 #pragma unroll
-                for (int kk = 0; kk < KC / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
-#ifdef SCA_MID_DEBUG
-                if (FWD && i0 == 0) { asm volatile("s_nop 0" :: "v"(acc)); DBG(20); }
-#endif
+                for (int s = 0; s < KC / 4; ++s) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s][0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s][1], acc[1], 0, 0, 0);
+                }
             } else {
-                // (columns of `act` and rows of the staged chunk past the data are zero: rounding kn up to 8 is harmless)
-                for (int k8 = 0; k8 < kn; k8 += 8) {
-                    float av[8], bv[8];
+                // (columns of `act` and rows of the staged chunk past the data are zero: rounding kn up to 4 is harmless)
+                for (int s4 = 0; s4 < kn; s4 += 4) {
+                    float av[4], bv[4][2];
 #pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        av[kk] = ap[2 * (k8 + kk)];
-                        bv[kk] = bp[2 * (k8 + kk) * MS_LD];
+                    for (int s = 0; s < 4; ++s) {
+                        av[s] = ap[4 * (s4 + s)];
+                        bv[s][0] = bp[4 * (s4 + s) * MS_LD];
+                        bv[s][1] = bp[4 * (s4 + s) * MS_LD + 16];
                     }
 #pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc, 0, 0, 0);
+                    for (int s = 0; s < 4; ++s) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s][0], acc[0], 0, 0, 0);
+                        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s][1], acc[1], 0, 0, 0);
+                    }
                 }
             }
         }
-        const int n = 32 * w + l31;
-        if (n < jn) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2) + 4 * half) * ldo + j0 + n] = acc[r];
+        for (int c = 0; c < 2; ++c) {
+            const int n = 32 * w + 16 * c + l16;
+            if (n < jn) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(4 * kg + r) * ldo + j0 + n] = acc[c][r];
+            }
         }
     }
     __syncthreads();
@@ -215,10 +224,9 @@ __device__ __forceinline__ void dropout_keep4(uint64_t seed, uint32_t stream, ui
     k[0] = u32_to_unit(r.x) > p; k[1] = u32_to_unit(r.y) > p; k[2] = u32_to_unit(r.z) > p; k[3] = u32_to_unit(r.w) > p;
 }
 
-__device__ __forceinline__ float row8_sum(float v) {      // sum over the 8 consecutive lanes that share a row
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
+__device__ __forceinline__ float row_sum(float v) {       // sum over the TPR consecutive lanes that share a row
+#pragma unroll
+    for (int m = 1; m < TPR; m <<= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
 
@@ -278,16 +286,15 @@ __device__ __forceinline__ void load_tile(float* __restrict__ dst, int ld, const
 }
 
 // Row epilogue of one layer (forward): pre -> (+bias, +Wc[:, c]) -> LayerNorm -> ReLU -> dropout.
-// 8 threads per row (all 32 rows of the tile in flight at once); thread t8 owns the 4-column groups 4 t8 + 32 q, so the
-// 8 threads of a row touch 128 contiguous bytes per group (16-byte HBM stores).  All HBM reads of the epilogue (bias,
-// condition column) are issued up front and the row lives in registers from then on: the chain is latency-bound, not
-// arithmetic-bound.
+// TPR = 16 threads per row (all 16 rows of the tile in flight at once); thread t owns the 4-column groups 4 t + 64 q, so
+// the threads of a row touch 256 contiguous bytes per group (16-byte HBM stores).  The row lives in registers from the
+// first read on: the chain is latency-bound, not arithmetic-bound.
 // The additive terms of a row epilogue (bias + condition column) depend on nothing the chain computes: they are
 // requested before the GEMM whose output the epilogue consumes and stay raw until then (see stage_load).
 template <int QM>
 __device__ __forceinline__ void epilogue_fwd_prefetch(const sca_mid_args& a, const sca_mid_layer& L, int r0,
                                                       float (&vb)[QM][4], float (&vc)[QM][4]) {
-    const int row = threadIdx.x >> 3, t8 = threadIdx.x & 7;
+    const int row = threadIdx.x / TPR, t8 = threadIdx.x % TPR;
     const int N = L.N;
     const int b = r0 + row;
     // absent terms read g_mid_blank and are dropped by the epilogue
@@ -296,7 +303,7 @@ __device__ __forceinline__ void epilogue_fwd_prefetch(const sca_mid_args& a, con
     for (int q = 0; q < QM; ++q)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int hc = min(32 * q + 4 * t8 + u, N - 1);
+            const int hc = min(CG * q + 4 * t8 + u, N - 1);
             const float* pb = L.bias ? L.bias + hc : g_mid_blank;
             const float* pc = L.Wc ? L.Wc + (long long)hc * a.C + c : g_mid_blank;
             vb[q][u] = *pb;
@@ -308,7 +315,7 @@ template <int QM>
 __device__ __forceinline__ void layer_epilogue_fwd(const sca_mid_args& a, const sca_mid_layer& L, const float* pre,
                                                    float* nxt, int ld, int r0, const float (&vb)[QM][4],
                                                    const float (&vc)[QM][4]) {
-    const int row = threadIdx.x >> 3, t8 = threadIdx.x & 7;
+    const int row = threadIdx.x / TPR, t8 = threadIdx.x % TPR;
     const int N = L.N, Npad = ((N + KC - 1) / KC) * KC;
     const int b = r0 + row;
     const bool live = b < a.B;
@@ -328,23 +335,23 @@ __device__ __forceinline__ void layer_epilogue_fwd(const sca_mid_args& a, const 
     for (int q = 0; q < QM; ++q)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int hh = 32 * q + 4 * t8 + u;
+            const int hh = CG * q + 4 * t8 + u;
             v[q][u] = (hh < N && live) ? v[q][u] + prow[hh] : 0.f;
             sum += v[q][u];
         }
     float mean = 0.f, rs = 1.f;
     if (a.norm == 1) {
-        mean = row8_sum(sum) / (float)N;
+        mean = row_sum(sum) / (float)N;
         float sq = 0.f;
 #pragma unroll
         for (int q = 0; q < QM; ++q)
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-                if (32 * q + 4 * t8 + u < N) {
+                if (CG * q + 4 * t8 + u < N) {
                     const float d = v[q][u] - mean;
                     sq = fmaf(d, d, sq);
                 }
-        rs = 1.0f / sqrtf(row8_sum(sq) / (float)N + 1e-5f);
+        rs = 1.0f / sqrtf(row_sum(sq) / (float)N + 1e-5f);
     }
     if (t8 == 0 && live) L.rs[b] = rs;
     const float keep_scale = a.p > 0.f ? 1.0f / (1.0f - a.p) : 1.f;
@@ -352,7 +359,7 @@ __device__ __forceinline__ void layer_epilogue_fwd(const sca_mid_args& a, const 
     float* nrow = nxt + row * ld;
 #pragma unroll
     for (int q = 0; q < QM; ++q) {
-        const int h4 = 32 * q + 4 * t8;
+        const int h4 = CG * q + 4 * t8;
         if (h4 >= Npad) continue;
         bool keep[4] = {true, true, true, true};
         if (a.p > 0.f && live && !L.mask) dropout_keep4(a.seed + stp, L.rng_stream, (uint32_t)b, (uint32_t)h4, a.p, keep);
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(256) void mid_fwd_kernel(const sca_mid_args a, int 
     // prefetch inside a branch has no fixed load count either).
     const int Z = a.Z;
     const int ng = a.n_enc + 1 + a.n_dec;
-    float wpre[NST], epb[2 * NS][4], epc[2 * NS][4];
+    float wpre[NST], epb[NS][4], epc[NS][4];
     auto gemm_ref = [&](int g, const float*& W, int& I, int& J) {     // operands of GEMM g (FWD: ldW = I)
         if (g == a.n_enc) { W = a.Wh; I = a.Kh; J = 2 * Z; return; }
         const sca_mid_layer& L = g < a.n_enc ? a.enc[g] : a.dec[g - a.n_enc - 1];
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(256) void mid_fwd_kernel(const sca_mid_args a, int 
         const bool head = g == a.n_enc, first = g < 0;
         // the layer whose epilogue follows (heads: none - `first` stands in for the prefetch, which tolerates a blank layer)
         const sca_mid_layer& L = (first || head) ? a.first : (g < a.n_enc ? a.enc[g] : a.dec[g - a.n_enc - 1]);
-        epilogue_fwd_prefetch<2 * NS>(a, L, r0, epb, epc);
+        epilogue_fwd_prefetch<NS>(a, L, r0, epb, epc);
         if (first) {
             // first encoder layer: sum of the GEMM's split-K slabs (its epilogue below)
             load_tile(oth, ld, a.pre0, a.S0, a.pre0_stride, r0, a.B, a.K0, a.K0);
@@ -455,7 +462,7 @@ __global__ __launch_bounds__(256) void mid_fwd_kernel(const sca_mid_args a, int 
         }
         DBG(1 + 2 * (g + 1));
         if (!head) {
-            layer_epilogue_fwd<2 * NS>(a, L, oth, cur, ld, r0, epb, epc);
+            layer_epilogue_fwd<NS>(a, L, oth, cur, ld, r0, epb, epc);
         } else {
             // heads -> reparameterised sample + KL
             const int Zp = ((Z + KC - 1) / KC) * KC;
@@ -511,7 +518,7 @@ __global__ __launch_bounds__(256) void mid_fwd_kernel(const sca_mid_args a, int 
 template <int QM>
 __device__ __forceinline__ void epilogue_bwd_prefetch(const sca_mid_args& a, const sca_mid_layer& L, bool none, int r0,
                                                       float (&y)[QM][4], float& rsv) {
-    const int row = threadIdx.x >> 3, t8 = threadIdx.x & 7;
+    const int row = threadIdx.x / TPR, t8 = threadIdx.x % TPR;
     const int N = L.N;
     const int b = r0 + row;
     const bool live = b < a.B;
@@ -522,7 +529,7 @@ __device__ __forceinline__ void epilogue_bwd_prefetch(const sca_mid_args& a, con
     const float* yb = have ? L.yn + bc * N : g_mid_blank;
 #pragma unroll
     for (int q = 0; q < QM; ++q) {
-        const int h4 = 32 * q + 4 * t8;
+        const int h4 = CG * q + 4 * t8;
         if (vec) {
             const float4 t = *reinterpret_cast<const float4*>(yb + (have ? min(h4, N - 4) : 0));
             y[q][0] = t.x; y[q][1] = t.y; y[q][2] = t.z; y[q][3] = t.w;
@@ -538,7 +545,7 @@ __device__ __forceinline__ void epilogue_bwd_prefetch(const sca_mid_args& a, con
 template <int QM>
 __device__ __forceinline__ void layer_epilogue_bwd(const sca_mid_args& a, const sca_mid_layer& L, const float* g,
                                                    float* dst, int ld, int r0, const float (&y)[QM][4], float rsv) {
-    const int row = threadIdx.x >> 3, t8 = threadIdx.x & 7;
+    const int row = threadIdx.x / TPR, t8 = threadIdx.x % TPR;
     const int N = L.N, Npad = ((N + KC - 1) / KC) * KC;
     const int b = r0 + row;
     const bool live = b < a.B;
@@ -551,7 +558,7 @@ __device__ __forceinline__ void layer_epilogue_bwd(const sca_mid_args& a, const 
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int q = 0; q < QM; ++q) {
-        const int h4 = 32 * q + 4 * t8;
+        const int h4 = CG * q + 4 * t8;
         bool keep[4] = {true, true, true, true};
         if (a.p > 0.f && live && !L.mask && h4 < N)
             dropout_keep4(a.seed + stp, L.rng_stream, (uint32_t)b, (uint32_t)h4, a.p, keep);
@@ -574,12 +581,12 @@ __device__ __forceinline__ void layer_epilogue_bwd(const sca_mid_args& a, const 
     }
     float m1 = 0.f, m2 = 0.f;
     if (a.norm == 1) {
-        m1 = row8_sum(s1) / (float)N;
-        m2 = row8_sum(s2) / (float)N;
+        m1 = row_sum(s1) / (float)N;
+        m2 = row_sum(s2) / (float)N;
     }
 #pragma unroll
     for (int q = 0; q < QM; ++q) {
-        const int h4 = 32 * q + 4 * t8;
+        const int h4 = CG * q + 4 * t8;
         if (h4 >= Npad) continue;
         float ov[4];
 #pragma unroll
@@ -616,7 +623,7 @@ __global__ __launch_bounds__(256) void mid_bwd_kernel(const sca_mid_args a, int 
     // activations of the NEXT epilogue requested one phase ahead - see mid_fwd_kernel.
     const int ng = a.n_enc + 1 + a.n_dec;
     const int gmin = a.fuse_first ? -1 : 0;
-    float wpre[NST], ypre[2 * NS][4], rspre = 0.f;
+    float wpre[NST], ypre[NS][4], rspre = 0.f;
     // layer of chain position g (g != n_enc; only references into the kernel arguments: a local stand-in would push
     // the whole argument block through private memory)
 #define MID_LAYER(g) ((g) < 0 ? a.first : ((g) < a.n_enc ? a.enc[(g)] : a.dec[(g) - a.n_enc - 1]))
@@ -631,7 +638,7 @@ __global__ __launch_bounds__(256) void mid_bwd_kernel(const sca_mid_args a, int 
         tile_gemm_prefetch<false>(wpre, W, ldW, I, J);
         const bool none = ng - 1 == a.n_enc;                 // (the heads have no epilogue)
         const sca_mid_layer& L = none ? a.first : a.dec[a.n_dec - 1];
-        epilogue_bwd_prefetch<2 * NS>(a, L, none, r0, ypre, rspre);
+        epilogue_bwd_prefetch<NS>(a, L, none, r0, ypre, rspre);
     }
     // upstream gradient tile: sum of the dX slabs of the output GEMM
     {
@@ -645,7 +652,7 @@ __global__ __launch_bounds__(256) void mid_bwd_kernel(const sca_mid_args a, int 
         const bool head = g == a.n_enc;
         if (!head) {
             const sca_mid_layer& L = MID_LAYER(g);
-            layer_epilogue_bwd<2 * NS>(a, L, cur, oth, ld, r0, ypre, rspre);                // oth = da [TM][N]
+            layer_epilogue_bwd<NS>(a, L, cur, oth, ld, r0, ypre, rspre);                // oth = da [TM][N]
         } else {
             // latent block: dz (+ dz2) + KL -> d[mean | log_var]
             const float akl = a.hyper[0] / (float)a.B;
@@ -678,7 +685,7 @@ __global__ __launch_bounds__(256) void mid_bwd_kernel(const sca_mid_args a, int 
             const bool none = gn < gmin || gn == a.n_enc;
             const int gs = none ? -1 : gn;
             const sca_mid_layer& Ln = MID_LAYER(gs);
-            epilogue_bwd_prefetch<2 * NS>(a, Ln, none, r0, ypre, rspre);
+            epilogue_bwd_prefetch<NS>(a, Ln, none, r0, ypre, rspre);
         }
         {
             const float* W; int ldW, I, J;
