@@ -226,7 +226,7 @@ int sca_grad_tail(const sca_tail_job* jobs, int n_jobs, void* stream);
  * Everything between the two wide GEMMs of a step in ONE launch per direction: the encoder layers after the first
  * (modules.py:52-97), the fused mean / log-var heads, sampling + KL (_base.py:391-407, trvae.py:143-147) and the decoder
  * hidden layers (modules.py:124-208), each with bias / one-hot condition column / LayerNorm / ReLU / dropout.  A
- * workgroup walks the chain for a tile of 32 cells with activations in LDS.  sca_mid_fwd reads h_in [B][K0] (output of
+ * workgroup walks the chain for a tile of 16 cells with activations in LDS.  sca_mid_fwd reads h_in [B][K0] (output of
  * the first encoder layer) and writes every tensor the unfused kernels write (yn, rs, h per layer, mu_lv, eps, z,
  * kl_row); sca_mid_bwd consumes the dX slabs of the output GEMM (dh, S, dh_stride) and optional dz2 [B][Z], writes the
  * per-layer da, dheads and dh_out [B][K0] (gradient w.r.t. h_in).  Layer widths <= sca_mid_max_width().  `a` is a HOST

@@ -663,7 +663,7 @@ class CVAEEngine:
     def _gemm(self, am, bm, A, lda, Bm, ldb, M, N, K, st, out=None, ldc=None, bias=None, force_s1=False,
               slab_key="slab", max_split=None):
         """Launch one GEMM; returns (ptr, S, slab_stride).  S == 1 with `out` writes the final tensor directly.
-        `max_split` caps the split-K count (the fused middle kernels sum the slabs serially per 32-row tile)."""
+        `max_split` caps the split-K count (the fused middle kernels sum the slabs per 16-row tile)."""
         L = self.lib
         S = 1 if force_s1 else L.sca_gemm_splitk_heuristic(M, N, K)
         if max_split is not None:
