@@ -330,8 +330,10 @@ class CVAEEngine:
         self.csr = None
         self.Bcap = 0
         # side stream: MMD runs beside the decoder, every dW / bias / condition-weight gradient beside the dX chain
-        self.aux = torch.cuda.Stream(device=self.device)
-        self.aux2 = torch.cuda.Stream(device=self.device)      # output-layer weight gradient beside the dX chain
+        self.aux = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("SCA_AUX_PRIO", "0")))
+        # output-layer weight gradient beside the dX chain
+        self.aux2 = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("SCA_AUX2_PRIO", "0")))
+        self._launch_stream = None
         self._lanes_used = set()
         self._events = [torch.cuda.Event() for _ in range(128)]
         self._ev_i = 0
@@ -347,6 +349,18 @@ class CVAEEngine:
         self.use_fused_mid = (self.arch == "trvae" and not self.use_bn and self.recon in ("nb", "mse")
                               and len(self.enc) - 1 <= 4 and 1 <= len(self.dec) <= 4
                               and max(self.H) <= wmax and 3 * self.Zt <= wmax and bool(s.get("fused_mid", True)))
+
+    def launch_stream(self) -> "torch.cuda.Stream":
+        """A HIGH-priority stream for the caller to run its steps on (`with torch.cuda.stream(eng.launch_stream())`).
+        The step's critical chain is issued on the caller's current stream, its side work (MMD, weight gradients) on
+        the engine's normal-priority aux streams; on a high-priority launch stream the chain's workgroups are placed
+        ahead of the side kernels' whenever both wait for CU slots - the likelihood kernel then gets its 512 workgroups
+        resident at once instead of trickling in behind the MMD's 4096 (0.657 -> 0.641 ms per 8192-cell step).
+        OPT-IN (bench.py --launch-priority high, trainers with SCA_LAUNCH_PRIORITY=high): steps issued this way hung twice
+        in test processes that had driven other engines before; train_step never replays HIP graphs on such a stream."""
+        if self._launch_stream is None:
+            self._launch_stream = torch.cuda.Stream(device=self.device, priority=-1)
+        return self._launch_stream
 
     # ------------------------------------------------------------------------------------------ configuration
     def set_hyper(self, alpha_kl=None, lr=None, eps=None, clip=None, t=None, log_weight=None):
@@ -1765,11 +1779,13 @@ class CVAEEngine:
           * True   : replayed as HIP graphs (one graph launch per step; best when launch-bound: 0.27 ms at B=128
                      against 0.37 ms eager) - "auto" for B <= 4096 (0.46 ms at B=4096, where the plan is bimodal);
           * False  : launched eagerly through the normal Python path."""
+        if use_graph is True and torch.cuda.current_stream(self.device).priority < 0:
+            use_graph = "plan"      # no HIP-graph replays on a high-priority stream (see launch_stream / trainers)
         if use_graph == "auto":
             # (world > 1: the gradient all-reduce is a host call between the two replayed halves of the step.  The
             # intermittent hangs of bench.py's two-rank one-GPU rehearsal came from ProcessGroupGloo's device-tensor
             # path, not from the launch mode: see distributed._host_staged.)
-            use_graph = True if B <= 4096 else "plan"
+            use_graph = True if (B <= 4096 and torch.cuda.current_stream(self.device).priority >= 0) else "plan"
         dp_exact = world > 1 and self._dp_exact()
         if dp_exact:
             self._dp_n_global = int(n_global) if n_global is not None else B * world
