@@ -914,11 +914,25 @@ static int mmd_rows_launch(const float* feat, int ld, const int32_t* cond, int B
     } else if (D <= 16) {
         const int nb = (row_n + MMD_T - 1) / MMD_T, jr = mmd_rows_jr(B, row_n);
         dim3 grid((nb + 3) / 4, ns);
+        // 40 KB of dynamic LDS are reserved per workgroup and never touched: with its ~2 KB of static LDS the kernel is
+        // then limited to THREE workgroups per CU (its registers allow four), which leaves a CU's fourth slot - 34 KB of
+        // LDS, a wave per SIMD - to the kernels of the step's critical chain that run beside it (output GEMM, likelihood):
+        // their workgroups otherwise trickle in behind the 4096 of this kernel.  Step at 8192 cells: 0.654 -> 0.645 ms;
+        // 24 KB (still four per CU): no change; 70 KB (two per CU): 0.695 ms.  SCA_MMD_LDS_PAD overrides (0 = off).
+        static const int pad = [] {
+            const char* v = getenv("SCA_MMD_LDS_PAD");
+            const int p = v ? atoi(v) : 40000;
+            if (p > 0) {
+                hipFuncSetAttribute((const void*)mmd_small_kernel<10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, p);
+                hipFuncSetAttribute((const void*)mmd_small_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, p);
+            }
+            return p > 0 ? p : 0;
+        }();
         if (D == 10)
-            hipLaunchKernelGGL((mmd_small_kernel<10, true>), grid, dim3(256), 0, st, feat, ld, cond, B, D, C, Wt,
+            hipLaunchKernelGGL((mmd_small_kernel<10, true>), grid, dim3(256), pad, st, feat, ld, cond, B, D, C, Wt,
                                loss_part, grad_slabs, slab_stride, jr, row_lo, row_n);
         else
-            hipLaunchKernelGGL((mmd_small_kernel<16, true>), grid, dim3(256), 0, st, feat, ld, cond, B, D, C, Wt,
+            hipLaunchKernelGGL((mmd_small_kernel<16, true>), grid, dim3(256), pad, st, feat, ld, cond, B, D, C, Wt,
                                loss_part, grad_slabs, slab_stride, jr, row_lo, row_n);
     } else {
         const int jt = (B + 15) / 16;
