@@ -10,7 +10,7 @@
 //   with Q[a][a] = number of pairs containing a, Q[a][b] = -1 for each selected pair (SURVEY a18 identity).
 // The gradient d mmd / d z_i = 4 sum_j Wt[c_i][c_j] K'(d2_ij) (z_i - z_j) is accumulated in the same pass
 // (K' = -sum_alpha exp(-d2/2alpha) / (2 alpha)).  The kernels are order-agnostic (any row order) and bound by the
-// quarter-rate v_exp_f32; see rbf19 and mmd_small_kernel for how the exp count per ordered pair is cut from 19 to ~4.5.
+// number of vector instructions; see rbf19 for how the 19 exps per ordered pair become 3 exps + one polynomial pair.
 #include "common.h"
 #include <type_traits>
 #include <stdlib.h>
@@ -30,26 +30,20 @@ __host__ __device__ constexpr float mmd_beta(int a) {
                                  20.f,  25.f,  30.f,  35.f,  100.f, 1e3f,  1e4f, 1e5f, 1e6f};
     return 1.f / (2.f * alpha[a]);
 }
-// The five widest bandwidths (alpha >= 100, beta <= 0.005) as ONE polynomial in d2:
-//   sum_a exp(-beta_a d2) = sum_k (-d2)^k S_k / k!,  sum_a beta_a exp(-beta_a d2) = sum_k (-d2)^k S_{k+1} / k!,
-//   S_k = sum_a beta_a^k.  Degree 7 on d2 <= 64 (beta d2 <= 0.32): truncation < 3e-9 relative.
-constexpr int MMD_WIDE0 = 14;
-constexpr int MMD_POLY_DEG = 7;
-constexpr float MMD_POLY_MAX_D2 = 64.f;
-__host__ __device__ constexpr double mmd_wide_S(int k) {
-    double s = 0.0;
-    for (int a = MMD_WIDE0; a < 19; ++a) {
-        double p = 1.0;
-        for (int i = 0; i < k; ++i) p *= (double)mmd_beta(a);
-        s += p;
-    }
-    return s;
-}
-__host__ __device__ constexpr double mmd_fact(int k) { return k <= 1 ? 1.0 : k * mmd_fact(k - 1); }
-template <int K> struct MmdPoly {
-    static constexpr float cK = (float)(((K & 1) ? -1.0 : 1.0) * mmd_wide_S(K) / mmd_fact(K));
-    static constexpr float cP = (float)(((K & 1) ? -1.0 : 1.0) * mmd_wide_S(K + 1) / mmd_fact(K));
-};
+// The ELEVEN bandwidths alpha >= 10 (beta <= 0.05) as one polynomial pair of degree 11 in t = d2 / 48 - 1 on
+// d2 <= 96: Chebyshev interpolation of  f = sum_a exp(-beta_a d2)  and  f' = sum_a beta_a exp(-beta_a d2)  in fp64
+// (scripts/mmd_poly_fit.py prints these arrays; float32 bandwidths as in MMD_BETA).  Fit error 4.6e-9 on f in [5.3, 11]
+// and 2.3e-10 on f' in [0.018, 0.165]; evaluated by an fp32 Horner chain the error is 1.3e-6 max / 2.5e-7 rms on f - one
+// rounding of a sum of that size, what the exp-by-exp accumulation leaves as well - and 2.1e-8 / 3.7e-9 on f'.
+constexpr int MMD_WIDE0 = 14;          // first of the five widest bandwidths (alpha >= 100)
+constexpr int MMD_PC_DEG = 11;
+constexpr float MMD_PC_MAX_D2 = 96.f;
+constexpr float MMD_PC_K[12] = {6.690013409e+00f, -2.189525604e+00f, 1.198144674e+00f, -5.572726727e-01f,
+                                2.325278521e-01f, -8.855332434e-02f, 3.069831803e-02f, -9.630272165e-03f,
+                                2.707465552e-03f, -6.992304698e-04f, 1.876339084e-04f, -3.961673065e-05f};
+constexpr float MMD_PC_Kp[12] = {4.561511800e-02f, -4.992268234e-02f, 3.482955322e-02f, -1.937758736e-02f,
+                                 9.224207141e-03f, -3.835581476e-03f, 1.404727227e-03f, -4.556471540e-04f,
+                                 1.307036582e-04f, -3.418900087e-05f, 9.257660167e-06f, -1.963592013e-06f};
 
 // Condition counts -> weight table Wt[C][C] (workgroup 0); the other workgroups clear `zero_buf` (the gradient
 // accumulator of the small-D kernel).  Counting looks at run boundaries so that condition-sorted minibatches cost
@@ -132,19 +126,14 @@ __global__ __launch_bounds__(256) void mmd_prepare_kernel(const int32_t* __restr
     }
 }
 
-// K = sum_a exp(-beta_a d2), Kp = sum_a beta_a exp(-beta_a d2) over the 19 bandwidths.  The kernel is bound by the
-// quarter-rate v_exp_f32, so the 19 exps are cut with two wave-uniform shortcuts that leave the values unchanged
-// to fp32 rounding:
-//   * alpha <= 0.01 (beta >= 50): 2^(-beta log2e d2) flushes to exactly 0 once beta log2e d2 > 126, i.e. for every
-//     lane with d2 > 1.75 - one ballot skips the five exps (taken for all but near-coincident pairs);
-//   * alpha >= 100: the five widest kernels are one degree-7 polynomial pair while every lane has d2 <= 64.
-// The nine bandwidths in between take one v_mul + one raw v_exp_f32 (2^x) + two accumulates each.
+// K = sum_a exp(-beta_a d2), Kp = sum_a beta_a exp(-beta_a d2) over the 19 bandwidths: three exps + one polynomial
+// pair in the common case - see rbf19 below.
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }   // v_pk_fma_f32
 
 // KK[u] = (K, Kp) of pair u.  Written for the packed fp32 VALU ops of gfx950 (two lanes of work per instruction):
 // the exp arguments of two pairs share one v_pk_mul_f32, each exp feeds (K, Kp) with one v_pk_fma_f32, and the two
-// Horner chains of the wide-bandwidth polynomial run as one packed chain.
+// Horner chains of the polynomial pair (rbf19) run as one packed chain.
 template <int U>
 __device__ __forceinline__ void rbf_terms(int a, const float (&d2)[U], v2f (&KK)[U]) {
     constexpr float LOG2E = 1.4426950408889634f;
@@ -192,7 +181,14 @@ __device__ __forceinline__ void rbf_mid(const float (&d2)[U], v2f (&KK)[U]) {
         KK[u] = pk_fma(v2f{e5, e5}, b5, KK[u]);
     }
 }
-// U independent pairs per call: the per-pair chains (exp -> accumulate, Horner) are latency-bound on their own
+// U independent pairs per call: the per-pair chains (exp -> accumulate, Horner) are latency-bound on their own.
+// Common case (every lane 1.75 <= d2 <= 96): THREE exps (alpha = 0.1, 1, 5) + the degree-11 polynomial pair for the
+// eleven bandwidths alpha >= 10 = 22 vector instructions per pair (the exp-by-exp form of the same sum took 42; the
+// kernels are bound by the number of vector instructions).
+//   * alpha <= 0.01 (beta >= 50): 2^(-beta log2e d2) flushes to exactly 0 once beta log2e d2 > 126, i.e. for every
+//     lane with d2 > 1.75 - one ballot skips the five exps (taken for all but near-coincident pairs);
+//   * some lane beyond the polynomial's range: every bandwidth by its own exp (squared chains for 20 -> 10 -> 5, 30 -> 15).
+// (the opaque copies pin the rarely needed exps inside their branches: hipcc otherwise speculates them)
 template <int U>
 __device__ __forceinline__ void rbf19(const float (&d2)[U], v2f (&KK)[U]) {
     bool near = false, far = false;
@@ -200,34 +196,39 @@ __device__ __forceinline__ void rbf19(const float (&d2)[U], v2f (&KK)[U]) {
     for (int u = 0; u < U; ++u) {
         KK[u] = v2f{0.f, 0.f};
         near |= d2[u] < 1.75f;
-        far |= d2[u] > MMD_POLY_MAX_D2;
-    }
-    rbf_mid<U>(d2, KK);
-    // (the opaque copies pin the rarely needed exps inside their branches: hipcc otherwise speculates them)
-    if (__ballot(near) != 0ull) {
-        float dn[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) { dn[u] = d2[u]; asm volatile("" : "+v"(dn[u])); }
-#pragma unroll
-        for (int a = 0; a < 5; ++a) rbf_terms<U>(a, dn, KK);
+        far |= d2[u] > MMD_PC_MAX_D2;
     }
     if (__ballot(far) == 0ull) {
-        v2f kp[U];
+        rbf_terms<U>(5, d2, KK);
+        rbf_terms<U>(6, d2, KK);
+        rbf_terms<U>(7, d2, KK);
+        v2f kp[U], tt[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) kp[u] = v2f{MmdPoly<7>::cK, MmdPoly<7>::cP};
-#define MMD_HORNER(N)                                                                               \
-        _Pragma("unroll") for (int u = 0; u < U; ++u)                                               \
-            kp[u] = pk_fma(kp[u], v2f{d2[u], d2[u]}, v2f{MmdPoly<N>::cK, MmdPoly<N>::cP});
-        MMD_HORNER(6) MMD_HORNER(5) MMD_HORNER(4) MMD_HORNER(3) MMD_HORNER(2) MMD_HORNER(1) MMD_HORNER(0)
-#undef MMD_HORNER
+        for (int u = 0; u < U; ++u) {
+            const float t = fmaf(d2[u], 2.0f / MMD_PC_MAX_D2, -1.0f);
+            tt[u] = v2f{t, t};
+            kp[u] = v2f{MMD_PC_K[MMD_PC_DEG], MMD_PC_Kp[MMD_PC_DEG]};
+        }
+#pragma unroll
+        for (int k = MMD_PC_DEG - 1; k >= 0; --k)
+#pragma unroll
+            for (int u = 0; u < U; ++u) kp[u] = pk_fma(kp[u], tt[u], v2f{MMD_PC_K[k], MMD_PC_Kp[k]});
 #pragma unroll
         for (int u = 0; u < U; ++u) KK[u] += kp[u];
     } else {
         float dw[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) { dw[u] = d2[u]; asm volatile("" : "+v"(dw[u])); }
+        rbf_mid<U>(dw, KK);
 #pragma unroll
         for (int a = MMD_WIDE0; a < 19; ++a) rbf_terms<U>(a, dw, KK);
+    }
+    if (__ballot(near) != 0ull) {
+        float dn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { dn[u] = d2[u]; asm volatile("" : "+v"(dn[u])); }
+#pragma unroll
+        for (int a = 0; a < 5; ++a) rbf_terms<U>(a, dn, KK);
     }
 }
 __device__ __forceinline__ void rbf19(float d2, float& K, float& Kp) {
