@@ -80,7 +80,7 @@ __device__ __attribute__((aligned(16))) float g_mid_blank[4];   // what an uncon
 constexpr int TM = 16;          // cells per workgroup
 constexpr int TPR = 256 / TM;   // threads per row in the row epilogues
 constexpr int CG = 4 * TPR;     // columns covered by one 4-column group per thread of a row
-constexpr int KC = 64;          // reduction chunk staged in LDS (64 deep: half as many exposed weight-fetch latencies)
+constexpr int KC = 32;          // reduction chunk staged in LDS
 constexpr int MS_LD = 129;      // leading dim of the staged weight chunk [KC][128] (+1: conflict-free transposed store)
 constexpr int MAXW = 256;       // widest supported layer
 constexpr int NST = KC * 128 / 256;   // staged weight values per thread and chunk
