@@ -77,6 +77,9 @@ namespace {
 
 __device__ __attribute__((aligned(16))) float g_mid_blank[4];   // what an unconditional prefetch reads for an absent operand
 
+#ifndef MID_WAVE_PRIO
+#define MID_WAVE_PRIO 3
+#endif
 constexpr int TM = 16;          // cells per workgroup
 constexpr int TPR = 256 / TM;   // threads per row in the row epilogues
 constexpr int CG = 4 * TPR;     // columns covered by one 4-column group per thread of a row
@@ -417,6 +420,9 @@ __global__ __launch_bounds__(256) void mid_fwd_kernel(const sca_mid_args a, int 
     const int r0 = blockIdx.x * TM;
     float* cur = A0;
     float* oth = A1;
+    // latency-bound chain on the step's critical path: when it shares a SIMD with the waves of a GEMM that saturates the
+    // matrix pipe (weight-gradient GEMMs on the side streams), its few MFMAs are issued first
+    __builtin_amdgcn_s_setprio(MID_WAVE_PRIO);
     warm_kernargs();
     DBG(15);
     // ONE loop walks the chain - first-layer epilogue (g = -1), encoder layers, heads + latent block (g = n_enc), decoder
@@ -617,6 +623,7 @@ __global__ __launch_bounds__(256) void mid_bwd_kernel(const sca_mid_args a, int 
     float* Ms = A1 + TM * ld;
     const int r0 = blockIdx.x * TM;
     const int Z = a.Z;
+    __builtin_amdgcn_s_setprio(MID_WAVE_PRIO);       // see mid_fwd_kernel
     warm_kernargs();
     // One loop walks the chain backwards (decoder layers, latent block + heads at g = n_enc, encoder layers, first-layer
     // epilogue at g = -1): one instance of the GEMM and of the epilogue, weights of the NEXT GEMM and the saved

@@ -718,13 +718,13 @@ class CVAEEngine:
             _lib.check(L.sca_splitk_reduce(p, S, stride, dst.data_ptr(), M * N, st), "splitk_reduce")
 
     # ---- gradient tail: slab sums and column reductions that only feed Adam, batched into one launch ------------
-    def _grad_gemm(self, am, bm, A, lda, Bm, ldb, M, N, K, st, dst):
+    def _grad_gemm(self, am, bm, A, lda, Bm, ldb, M, N, K, st, dst, allow_kk=True):
         """Weight-gradient GEMM into `dst` [M, N]: split-K slabs go to a region of their own and their sum becomes a
         job of the tail kernel (instead of a sca_splitk_reduce launch per tensor)."""
         L = self.lib
         rec = getattr(self, "record_gemms", None)
         # large dY^T X products: the register-direct k-major kernel (gemm_f32.hip, gemm_kk_kernel), one launch each
-        if (am == 1 and bm == 1 and M * N >= self.KK_MIN_MN and K >= 1024
+        if (allow_kk and am == 1 and bm == 1 and M * N >= self.KK_MIN_MN and K >= 1024
                 and L.sca_gemm_kk_supported(A, lda, Bm, ldb, M, N)):
             S = L.sca_gemm_kk_splitk_heuristic(M, N, K)
             if S == 1:
@@ -1305,7 +1305,10 @@ class CVAEEngine:
 
         def recon_side(sa):
             if T[self.out_w]:
-                self._grad_gemm(1, 1, dl, G, h_last, Hd, G, Hd, B, sa, Gd[self.out_w])
+                # (tiled GEMM, not the register-direct one: its small workgroups leave the CUs to mid_bwd sooner - mid_bwd
+                #  73 -> 62 us inside the 8192-cell step, step -2.5 us; SCA_OUT_DW_KK=1 for A/B)
+                self._grad_gemm(1, 1, dl, G, h_last, Hd, G, Hd, B, sa, Gd[self.out_w],
+                                allow_kk=os.environ.get("SCA_OUT_DW_KK", "0") == "1")
             if self.has_theta and T["theta"]:
                 _lib.check(L.sca_transpose_scale(ws["dthetaT"].data_ptr(), max(C, 1), G, -1.0 / B,
                                                  Gd["theta"].data_ptr(), sa), "transpose_scale")
