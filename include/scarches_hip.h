@@ -167,6 +167,12 @@ int sca_mmd_fwd_bwd_prepared(const float* feat, int ld, const int32_t* cond, int
  * and the owner gradients with v_mfma_f32_16x16x4_f32 (D <= 10; same outputs, different slab / partial counts - call
  * before sizing workspaces with sca_mmd_*_num_slabs / _num_partials).  Returns the previous selection. */
 int sca_mmd_select_form(int form);
+/* Scheduling hook, process-wide, no effect on results: bytes of LDS (0..65536, default 40000) each workgroup of the
+ * vector-ALU row-block kernel reserves without touching them, which caps its workgroups per CU (40000 -> three) and so
+ * leaves room for the kernels launched beside it.  Applies to launches issued after the call; the environment variable
+ * SCA_MMD_LDS_PAD overrides it.  Returns 0, -1 for a size out of range.  No counterpart in the reference (a stream-
+ * schedule knob of this implementation). */
+int sca_mmd_reserve_lds(int bytes);
 /* Row-block form for data-parallel training (same reference lines; SURVEY 8(e) exception 1: the reference's MMD
  * couples every pair of cells of the global minibatch).  feat / cond hold the all-gathered minibatch [B]; the launch
  * evaluates rows [row_lo, row_lo + row_n) against all B columns: loss partials = the block's share of the MMD (the

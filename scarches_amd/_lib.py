@@ -87,6 +87,7 @@ SIGNATURES = {
     "sca_mmd_num_partials": [I, I],
     "sca_mmd_fwd_bwd": [P, I, P, I, I, I, I, F, P, P, P, P, LL, P],
     "sca_mmd_select_form": [I],
+    "sca_mmd_reserve_lds": [I],
     "sca_mmd_prepare": [P, I, I, I, F, P, P, P],
     "sca_mmd_prepared_supported": [I, I],
     "sca_mmd_fwd_bwd_prepared": [P, I, P, I, I, I, P, I, I, P, P, LL, P],

@@ -13,6 +13,8 @@
 // number of vector instructions; see rbf19 for how the 19 exps per ordered pair become 3 exps + one polynomial pair.
 #include "common.h"
 #include <type_traits>
+#include <algorithm>
+#include <atomic>
 #include <stdlib.h>
 
 namespace {
@@ -806,6 +808,16 @@ extern "C" int sca_mmd_select_form(int form) {
     if (form == 0 || form == 1) g_mmd_form = form;
     return prev;
 }
+// Bytes of LDS the vector-ALU row-block kernel reserves per workgroup without using them (see mmd_rows_launch): a
+// scheduling knob - it caps the kernel's workgroups per CU - with no effect on results.  Process-wide; applies to the
+// launches issued after the call.  Returns 0, or -1 for a size outside [0, 65536].
+constexpr int MMD_PAD_MAX = 65536;
+static std::atomic<int> g_mmd_pad{40000};
+extern "C" int sca_mmd_reserve_lds(int bytes) {
+    if (bytes < 0 || bytes > MMD_PAD_MAX) return -1;
+    g_mmd_pad.store(bytes, std::memory_order_relaxed);
+    return 0;
+}
 static bool mmd_use_mfma(int D) { return g_mmd_form == 1 && D <= 10; }
 static int mmd_mfma_per_range(int B, int row_n) {
     const long long ob = (row_n + 63) / 64;
@@ -915,20 +927,20 @@ static int mmd_rows_launch(const float* feat, int ld, const int32_t* cond, int B
     } else if (D <= 16) {
         const int nb = (row_n + MMD_T - 1) / MMD_T, jr = mmd_rows_jr(B, row_n);
         dim3 grid((nb + 3) / 4, ns);
-        // 40 KB of dynamic LDS are reserved per workgroup and never touched: with its ~2 KB of static LDS the kernel is
-        // then limited to THREE workgroups per CU (its registers allow four), which leaves a CU's fourth slot - 34 KB of
-        // LDS, a wave per SIMD - to the kernels of the step's critical chain that run beside it (output GEMM, likelihood):
-        // their workgroups otherwise trickle in behind the 4096 of this kernel.  Step at 8192 cells: 0.654 -> 0.645 ms;
-        // 24 KB (still four per CU): no change; 70 KB (two per CU): 0.695 ms.  SCA_MMD_LDS_PAD overrides (0 = off).
-        static const int pad = [] {
+        // `pad` bytes of dynamic LDS are reserved per workgroup and never touched (default 40000): with its ~2 KB of
+        // static LDS the kernel is then limited to THREE workgroups per CU (its registers allow four), which leaves a
+        // CU's fourth slot - 34 KB of LDS, a wave per SIMD - to the kernels of the step's critical chain that run beside
+        // it (output GEMM, likelihood): their workgroups otherwise trickle in behind the 4096 of this kernel.  Step at
+        // 8192 cells with the MMD forked in front of the output GEMM: 0.654 -> 0.645 ms; 24 KB (still four per CU): no
+        // change; 70 KB (two per CU): 0.695 ms.  sca_mmd_reserve_lds() sets it per launch sequence (the engine drops
+        // the cap when it forks the MMD behind the likelihood kernel's launch); SCA_MMD_LDS_PAD overrides both.
+        static const int env_pad = [] {
             const char* v = getenv("SCA_MMD_LDS_PAD");
-            const int p = v ? atoi(v) : 40000;
-            if (p > 0) {
-                hipFuncSetAttribute((const void*)mmd_small_kernel<10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, p);
-                hipFuncSetAttribute((const void*)mmd_small_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, p);
-            }
-            return p > 0 ? p : 0;
+            hipFuncSetAttribute((const void*)mmd_small_kernel<10, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MMD_PAD_MAX);
+            hipFuncSetAttribute((const void*)mmd_small_kernel<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, MMD_PAD_MAX);
+            return v ? std::min(std::max(atoi(v), 0), MMD_PAD_MAX) : -1;
         }();
+        const int pad = env_pad >= 0 ? env_pad : g_mmd_pad.load(std::memory_order_relaxed);
         if (D == 10)
             hipLaunchKernelGGL((mmd_small_kernel<10, true>), grid, dim3(256), pad, st, feat, ld, cond, B, D, C, Wt,
                                loss_part, grad_slabs, slab_stride, jr, row_lo, row_n);

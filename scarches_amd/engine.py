@@ -51,6 +51,9 @@ _QUERIES = {"sca_gemm_kk_supported", "sca_gemm_kk_splitk_heuristic", "sca_mid_ma
 # gains (0.684 ms per step in one launch; 0.794 / 0.779 / 0.763 ms with 0.4 / 0.5 / 0.6).
 MMD_SPLIT_MIN = int(os.environ.get("SCA_MMD_SPLIT_MIN", 4096))
 MMD_SPLIT_FRAC = float(os.environ.get("SCA_MMD_SPLIT_FRAC", 0.0))
+MMD_AFTER_OUT = os.environ.get("SCA_MMD_AFTER_OUT", "auto")      # "0" / "1" / "auto": see _fused_path
+MMD_AFTER_OUT_MAX = int(os.environ.get("SCA_MMD_AFTER_OUT_MAX", 8192))
+MMD_PAD, MMD_PAD_AFTER_OUT = 40000, 24000       # sca_mmd_reserve_lds per fork point (SCA_MMD_LDS_PAD overrides both)
 
 
 class _RecordingLib:
@@ -1253,6 +1256,13 @@ class CVAEEngine:
                 and 0.0 < MMD_SPLIT_FRAC < 1.0):
             n1 = max(256, (int(B * MMD_SPLIT_FRAC) // 256) * 256)
         mmd_split = n1 < B
+        # Where the MMD forks off.  Up to MMD_AFTER_OUT_MAX cells: behind the output GEMM, so that the likelihood kernel
+        # (which follows that GEMM directly on the main stream) is placed on the CUs first and the MMD fills what is
+        # left - forked earlier, the MMD's 4096 workgroups hold the CUs and the likelihood workgroups trickle in behind
+        # them (likelihood 215 -> 165 us, step 0.632 -> 0.612 ms at 8192 cells).  Above: the MMD (quadratic in the
+        # cells) is the longer of the two and keeps its early start beside the output GEMM (16384: 1.38 vs 1.41 ms).
+        after_out = (do_mmd and not mmd_split and compute_grad and self.overlap
+                     and (MMD_AFTER_OUT == "1" or (MMD_AFTER_OUT == "auto" and B <= MMD_AFTER_OUT_MAX)))
         if do_mmd:
             if mmd_split:
                 nA = L.sca_mmd_rows_num_partials(B, n1, Z)
@@ -1265,15 +1275,24 @@ class CVAEEngine:
 
                 def mmd_work(sa):
                     self._mmd_launch(sa, ws["z"], Z, self._cond_cur, cond_p, B, compute_grad)
-            self._defer(mmd_work)
-        ev_side = self._flush()
+            # (the MMD's cap of three workgroups per CU keeps a slot free for kernels that arrive AFTER it; forked behind
+            #  the likelihood kernel's predecessor it needs none: 0.632 ms with the cap, 0.612 without at 8192 cells)
+            _lib.check(L.sca_mmd_reserve_lds(MMD_PAD_AFTER_OUT if after_out else MMD_PAD), "mmd_reserve_lds")
+            if not after_out:
+                self._defer(mmd_work)
+        ev_side = None if after_out else self._flush()
         Hd = self.dec[-1].n_out
         h_last = ws[self.dec[-1].tag + ".h"].data_ptr()
+        if after_out:
+            self._wait(self._ev_pro)
         self._gemm(0, 0, h_last, Hd, P[self.out_w].data_ptr(), Hd, B, G, Hd, st, out=ws["logits"].data_ptr(), ldc=G,
                    bias=P[self.out_b].data_ptr(), force_s1=True)
+        if after_out:
+            self._defer(mmd_work)
         # (measured: with this wait moved in front of the output GEMM - to spare the stream operation between the GEMM
         #  and the likelihood kernel - the GEMM is dispatched behind the MMD, which then holds every CU: 0.665 -> 0.753 ms)
-        self._wait(self._ev_pro)
+        if not after_out:
+            self._wait(self._ev_pro)
         rpb = _recon_rows_per_block(B)
         gob = self.g[self.out_b].data_ptr() if T[self.out_b] else None
         if self.recon == "mse":
@@ -1288,6 +1307,8 @@ class CVAEEngine:
                                         ws["row_ll"].data_ptr(), ws["dthetaT"].data_ptr(), gob, None,
                                         int(compute_grad), None, None, st), "recon_rows")
             recon_sign = -1.0
+        if after_out:
+            ev_side = self._flush()
         ev_mmd2 = None
         if mmd_split:
             ev_mmd2 = self._next_event()
@@ -1305,10 +1326,10 @@ class CVAEEngine:
 
         def recon_side(sa):
             if T[self.out_w]:
-                # (tiled GEMM, not the register-direct one: its small workgroups leave the CUs to mid_bwd sooner - mid_bwd
-                #  73 -> 62 us inside the 8192-cell step, step -2.5 us; SCA_OUT_DW_KK=1 for A/B)
+                # (register-direct kernel; SCA_OUT_DW_KK=0 = the tiled GEMM, whose small workgroups leave the CUs to
+                #  mid_bwd sooner: it won 2.5 us while the MMD forked before the output GEMM, and loses 6 us now)
                 self._grad_gemm(1, 1, dl, G, h_last, Hd, G, Hd, B, sa, Gd[self.out_w],
-                                allow_kk=os.environ.get("SCA_OUT_DW_KK", "0") == "1")
+                                allow_kk=os.environ.get("SCA_OUT_DW_KK", "1") == "1")
             if self.has_theta and T["theta"]:
                 _lib.check(L.sca_transpose_scale(ws["dthetaT"].data_ptr(), max(C, 1), G, -1.0 / B,
                                                  Gd["theta"].data_ptr(), sa), "transpose_scale")
