@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--latent", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="gather each minibatch at the head of its own step instead of beside the previous step's tail")
     ap.add_argument("--dp-mmd", choices=["local", "exact"], default="local",
                     help="N > 1 only: MMD over each rank's slice (default: weak scaling keeps the O(B^2) MMD work per "
                          "GPU fixed) or the reference's MMD over the global minibatch (all-gather of z; O(B_global^2) "
@@ -275,11 +277,15 @@ def main():
         return dt
 
     def run_on_stream(Bx, steps, warmup):
-        ids, cs = epoch_batches(cond_all, steps + warmup, Bx, gen)
+        # (one minibatch more than steps: the loader runs one minibatch ahead - every timed step gathers one, the
+        #  first timed step trains on the one the last warm-up step gathered, the last gathers one nobody trains on)
+        ids, cs = epoch_batches(cond_all, steps + warmup + 1, Bx, gen)
         def one(i):
-            # gather -> fwd -> bwd -> (RCCL gradient all-reduce) -> Adam; see --launch
+            # fwd -> bwd -> (RCCL gradient all-reduce) -> Adam, with the CSR gather of minibatch i + 1 beside the
+            # gradient tail (--no-prefetch: gather of minibatch i at the head of the step instead); see --launch
             eng.train_step(ids[i], cs[i], Bx, alpha_kl=0.5, lr=1e-3, eps=0.01, clip=0.0, weight_decay=0.04,
-                           world=world, use_graph={"auto": "auto", "plan": "plan", "graph": True, "eager": False}[a.launch])
+                           world=world, use_graph={"auto": "auto", "plan": "plan", "graph": True, "eager": False}[a.launch],
+                           next_rows=None if a.no_prefetch else ids[i + 1])
         for i in range(warmup):
             one(i)
         if world > 1:
@@ -323,7 +329,7 @@ def main():
                                f"{data.numel() / n_local:.0f} nnz/cell), {C} conditions, NB loss, MMD on z, hidden {H}, "
                                f"Z={Z}, dropout 0.05, Adam(eps 0.01, wd 0.04)",
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}" if world > 1 else "single",
-                   "launch": a.launch,
+                   "launch": a.launch, "loader": "in-step" if a.no_prefetch else "one minibatch ahead",
                    "mmd": "single device" if world == 1 else
                           ("global minibatch (all-gather of z)" if a.dp_mmd == "exact" else "per-rank slice")},
         "final_losses": {"recon": losses[0], "kl": losses[1], "mmd": losses[2]},

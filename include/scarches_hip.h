@@ -204,6 +204,14 @@ int sca_begin_step(float* hyper, uint32_t* step_ctr, float alpha_kl, float lr, f
 int sca_begin_step_batch(float* hyper, uint32_t* step_ctr, float alpha_kl, float lr, float bias_corr1,
                          float bias_corr2_sqrt, float eps, float clip, const int64_t* rows_src, int64_t* rows_dst,
                          const int32_t* cond_src, int32_t* cond_dst, int B, void* stream);
+/* ... plus the row ids [B_next] of the NEXT minibatch into next_dst: the engine's training step gathers minibatch
+ * n + 1 into the dense input buffer beside the gradient tail and Adam of step n (the role the reference gives its
+ * DataLoader workers, trainers/trvae/trainer.py:171-181 n_workers; here the loader is a kernel, so the
+ * overlap is a stream schedule).  B_next = 0: same as sca_begin_step_batch. */
+int sca_begin_step_batch_next(float* hyper, uint32_t* step_ctr, float alpha_kl, float lr, float bias_corr1,
+                              float bias_corr2_sqrt, float eps, float clip, const int64_t* rows_src,
+                              int64_t* rows_dst, const int32_t* cond_src, int32_t* cond_dst, int B,
+                              const int64_t* next_src, int64_t* next_dst, int B_next, void* stream);
 int sca_fill_zero(void* p, long long bytes, void* stream);
 int sca_finalize_losses(const float* row_recon, float recon_sign, const float* row_kl, int B, const double* mmd_part,
                         int n_part, const float* hyper, float* losses, double* accum, void* stream);

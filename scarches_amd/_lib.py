@@ -98,6 +98,7 @@ SIGNATURES = {
     "sca_finalize_losses": [P, F, P, I, P, I, P, P, P, P],
     "sca_begin_step": [P, P, F, F, F, F, F, F, P],
     "sca_begin_step_batch": [P, P, F, F, F, F, F, F, P, P, P, P, I, P],
+    "sca_begin_step_batch_next": [P, P, F, F, F, F, F, F, P, P, P, P, I, P, P, I, P],
     "sca_fill_zero": [P, LL, P],
     "sca_masked_copy": [P, I, P, I, P, I, I, I, P],
     "sca_masked_max_cols": [],

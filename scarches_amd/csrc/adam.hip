@@ -80,7 +80,9 @@ __global__ __launch_bounds__(256) void begin_step_batch_kernel(float* __restrict
                                                                const int64_t* __restrict__ rows_src,
                                                                int64_t* __restrict__ rows_dst,
                                                                const int32_t* __restrict__ cond_src,
-                                                               int32_t* __restrict__ cond_dst, int B) {
+                                                               int32_t* __restrict__ cond_dst, int B,
+                                                               const int64_t* __restrict__ next_src,
+                                                               int64_t* __restrict__ next_dst, int B_next) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0) {
         hyper[0] = a; hyper[1] = lr; hyper[2] = bc1; hyper[3] = bc2s; hyper[4] = eps; hyper[5] = clip;
@@ -90,18 +92,34 @@ __global__ __launch_bounds__(256) void begin_step_batch_kernel(float* __restrict
         if (rows_dst) rows_dst[i] = rows_src[i];
         if (cond_dst) cond_dst[i] = cond_src[i];
     }
+    if (i < B_next) next_dst[i] = next_src[i];
 }
 
 }  // namespace
 
+extern "C" int sca_begin_step_batch_next(float*, uint32_t*, float, float, float, float, float, float, const int64_t*,
+                                         int64_t*, const int32_t*, int32_t*, int, const int64_t*, int64_t*, int, void*);
 extern "C" int sca_begin_step_batch(float* hyper, uint32_t* step_ctr, float alpha_kl, float lr, float bias_corr1,
                                     float bias_corr2_sqrt, float eps, float clip, const int64_t* rows_src,
                                     int64_t* rows_dst, const int32_t* cond_src, int32_t* cond_dst, int B,
                                     void* stream) {
-    if (B < 0 || (rows_dst && !rows_src) || (cond_dst && !cond_src)) return -1;
-    const int nb = B > 0 ? (B + 255) / 256 : 1;
+    return sca_begin_step_batch_next(hyper, step_ctr, alpha_kl, lr, bias_corr1, bias_corr2_sqrt, eps, clip, rows_src,
+                                     rows_dst, cond_src, cond_dst, B, nullptr, nullptr, 0, stream);
+}
+
+// ... and the row ids of the NEXT minibatch into the static buffer the step's trailing gather reads (the engine gathers
+// minibatch n + 1 beside the gradient tail and Adam of step n: CVAEEngine.train_step(next_rows=...)).
+extern "C" int sca_begin_step_batch_next(float* hyper, uint32_t* step_ctr, float alpha_kl, float lr, float bias_corr1,
+                                         float bias_corr2_sqrt, float eps, float clip, const int64_t* rows_src,
+                                         int64_t* rows_dst, const int32_t* cond_src, int32_t* cond_dst, int B,
+                                         const int64_t* next_src, int64_t* next_dst, int B_next, void* stream) {
+    if (B < 0 || B_next < 0 || (rows_dst && !rows_src) || (cond_dst && !cond_src)) return -1;
+    if (B_next > 0 && (!next_src || !next_dst)) return -1;
+    const int n = B > B_next ? B : B_next;
+    const int nb = n > 0 ? (n + 255) / 256 : 1;
     hipLaunchKernelGGL(begin_step_batch_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, hyper, step_ctr, alpha_kl,
-                       lr, bias_corr1, bias_corr2_sqrt, eps, clip, rows_src, rows_dst, cond_src, cond_dst, B);
+                       lr, bias_corr1, bias_corr2_sqrt, eps, clip, rows_src, rows_dst, cond_src, cond_dst, B, next_src,
+                       next_dst, B_next);
     SCA_CHECK_LAUNCH();
     return 0;
 }

@@ -342,6 +342,9 @@ class CVAEEngine:
         self._ev_i = 0
         self._aux_q = []
         self._rec = None                # launch-plan recorder (train_step)
+        self._pf = None                 # minibatch that ws["x"] already holds (train_step(next_rows=...))
+        self._pf_flags = (False, False) # (skip the gather at the head of the step, gather the next one at its end)
+        self._rows_next = None
         self.overlap = True
         self._dp = None                 # set_dp(): rank / world / exact-MMD switch of data-parallel runs
         self._dp_ws = {}
@@ -806,13 +809,13 @@ class CVAEEngine:
         self._tail_jobs.append((1, 0, 0, da, db or 0, 0, dWc or 0, (cond_p or 0) if dWc else 0, B, H,
                                 C if dWc else 0))
 
-    def _defer_tail(self, join=()):
-        """Gradient tail on lane 0 and - single-device train_step - Adam right behind it on the same stream (no
+    def _defer_tail(self, join=(), lane=0):
+        """Gradient tail on an aux stream and - single-device train_step - Adam right behind it on the same stream (no
         cross-stream hop between the last reduction and the update)."""
-        self._defer(self._run_tail, join=join)
+        self._defer(self._run_tail, lane=lane, join=join)
         fused = self._adam_after_tail
         if fused is not None:
-            self._defer(lambda sa: self.adam_step(fused[0], fused[1], stream=sa))
+            self._defer(lambda sa: self.adam_step(fused[0], fused[1], stream=sa), lane=lane)
             self._adam_done = True
 
     def _run_tail(self, st):
@@ -897,10 +900,13 @@ class CVAEEngine:
         if x_dense is not None:
             _lib.check(L.sca_dense_gather_rows(ptr(x_dense), x_dense.stride(0), ptr(row_ids), B, G, log1p,
                                                ws["x"].data_ptr(), G, ws["sf"].data_ptr(), st), "dense_gather")
+            self._pf = None
         else:
             ip, ix, dv = self.csr
-            _lib.check(L.sca_csr_gather_rows(ip.data_ptr(), ix.data_ptr(), dv.data_ptr(), ptr(row_ids), B, G, log1p,
-                                             ws["x"].data_ptr(), G, ws["sf"].data_ptr(), st), "csr_gather")
+            if not self._pf_flags[0]:       # (True: the previous step already gathered this minibatch, train_step)
+                _lib.check(L.sca_csr_gather_rows(ip.data_ptr(), ix.data_ptr(), dv.data_ptr(), ptr(row_ids), B, G, log1p,
+                                                 ws["x"].data_ptr(), G, ws["sf"].data_ptr(), st), "csr_gather")
+                self._pf = None
 
         self._aux_q = []
         self._lanes_used = set()
@@ -1369,6 +1375,8 @@ class CVAEEngine:
         self._layer_backward(self.enc[0], ws["x"].data_ptr(), None, 0, 0, None, False, B, cond_p, p_drop, masks, st,
                              have_da=True, side_out=sides)
 
+        do_next = self._pf_flags[1]
+
         def weight_side(sa):      # the wide first-layer dY^T X: register-direct kernel on the aux stream
             self._gg_jobs = []
             try:
@@ -1377,6 +1385,11 @@ class CVAEEngine:
             finally:
                 jobs, self._gg_jobs = self._gg_jobs, None
             self._launch_group(jobs, sa)        # (only when the first layer did not qualify for the kk kernel)
+        def gather_next(sa):
+            ip, ix, dv = self.csr
+            _lib.check(L.sca_csr_gather_rows(ip.data_ptr(), ix.data_ptr(), dv.data_ptr(), self._rows_next.data_ptr(),
+                                             B, G, 0 if self.recon == "mse" else 1, ws["x"].data_ptr(), G,
+                                             ws["sf"].data_ptr(), sa), "csr_gather[next]")
         self._defer(weight_side)
         # ... and beside it, on the main stream (idle after mid_bwd), ONE grouped launch for every narrow layer
         self._gg_jobs = []
@@ -1387,8 +1400,21 @@ class CVAEEngine:
         self._launch_group(jobs, st)
         # (measured: gradient tail + Adam on the main stream instead, so that the next step queues behind Adam without
         #  a cross-stream hop: 0.6640 -> 0.6626 ms, within noise - the ~15 us between Adam and the next step's first
-        #  kernel is dispatch latency, not the hop; the host enqueues a step in 0.39 ms and stays ahead)
-        self._defer_tail(join=(1,))
+        #  kernel is dispatch latency, not the hop; the host enqueues a step in 0.39 ms and stays ahead.  Again with the
+        #  first-layer weight gradient on the main stream too and the grouped GEMM on the aux stream: the two GEMMs then
+        #  start together and take 64 / 61 us instead of 51 / 41, and the tail still starts 17 us behind them - the waits
+        #  for the aux streams' events cost that whether or not the events have fired: 0.599 -> 0.604 ms)
+        if not do_next:
+            self._defer_tail(join=(1,))
+        else:
+            # The NEXT minibatch's gather (train_step(next_rows=...)): on the first aux stream, directly behind the last
+            # reader of ws["x"] (the first-layer weight gradient above, same stream: no event needed), while the
+            # gradient tail and Adam move to the second aux stream and run beside it - the step that follows starts at
+            # its first GEMM.  Same kernel, same inputs as the in-line gather at the head of a step.
+            # (An event recorded on the first aux stream behind that GEMM and waited for on the second - gather there,
+            #  tail staying here - crashed hipStreamEndCapture when the step was captured into a HIP graph.)
+            self._defer_tail(join=(0,), lane=1)
+            self._defer(gather_next, lane=0, reuse=True)
         self._wait(self._flush())
         return self.losses
 
@@ -1791,7 +1817,7 @@ class CVAEEngine:
 
     # ------------------------------------------------------------------------------------------ whole step
     def train_step(self, row_ids, cond, B, alpha_kl, lr, eps=0.01, clip=0.0, weight_decay=0.04, world=1,
-                   use_graph="auto", wd_overrides=None, grad_weight=None, n_global=None):
+                   use_graph="auto", wd_overrides=None, grad_weight=None, n_global=None, next_rows=None):
         """One optimisation step: forward + backward (+ gradient all-reduce) + Adam.
 
         All per-step scalars live in device memory (`hyper`, `step_ctr`) and the minibatch ids are copied into static
@@ -1802,7 +1828,13 @@ class CVAEEngine:
                      beside the likelihood kernel instead of beside the output GEMM: 0.84 vs 0.77 ms at B=8192);
           * True   : replayed as HIP graphs (one graph launch per step; best when launch-bound: 0.27 ms at B=128
                      against 0.37 ms eager) - "auto" for B <= 4096 (0.46 ms at B=4096, where the plan is bimodal);
-          * False  : launched eagerly through the normal Python path."""
+          * False  : launched eagerly through the normal Python path.
+
+        `next_rows` (int64 device tensor, same size as `row_ids`): the row ids of the minibatch the NEXT call will
+        train on.  The recorded step then ends with that minibatch's CSR gather - on an aux stream, beside the gradient
+        tail and Adam - and the next call, given the same tensor (same storage, unmodified), starts at its first GEMM
+        instead of the gather: the loader runs ahead of the model as the reference's DataLoader workers do.  Results
+        are those of the un-pipelined sequence (same kernel, same inputs, same order of the arithmetic)."""
         if use_graph is True and torch.cuda.current_stream(self.device).priority < 0:
             use_graph = "plan"      # no HIP-graph replays on a high-priority stream (see launch_stream / trainers)
         if use_graph == "auto":
@@ -1821,6 +1853,7 @@ class CVAEEngine:
                 use_graph = "plan"
         if use_graph is False:
             self.begin_step(alpha_kl, lr, eps, clip)
+            self._pf_flags = (False, False)
             self._step_and_adam(row_ids, cond, B, weight_decay, wd_overrides, world > 1)
             if world > 1:
                 self._allreduce_and_adam(world, grad_weight, weight_decay, wd_overrides)
@@ -1830,8 +1863,26 @@ class CVAEEngine:
                     tuple(sorted(k for k, v in self.trainable.items() if v)), self.use_mmd, self.mmd_on,
                     self.boundary, self.beta, torch.cuda.current_stream(self.device).cuda_stream,
                     self._dp_n_global if dp_exact else None, self.hsic_beta, self.dr_rate, self.seed, self.freeze,
-                    self._ws_gen)
+                    self._ws_gen, self._pf_flags)
         self._ensure(B)
+        # (launch plans only: captured into a HIP graph the trailing gather costs more than the head gather it
+        #  replaces - 0.350 -> 0.360 ms at 4096 cells, 0.239 -> 0.245 ms at 1024)
+        do_next = next_rows is not None and use_graph == "plan" and self._pf_possible(next_rows, B)
+        if do_next and (self._rows_next is None or self._rows_next.numel() < B):
+            torch.cuda.synchronize(self.device)
+            self._rows_next = torch.zeros(max(B, self.Bcap), dtype=torch.int64, device=self.device)
+            self._invalidate()
+        have_cur = self._pf_matches(row_ids, B)
+        self._pf_flags = (have_cur, do_next)
+        try:
+            return self._train_step_planned(row_ids, cond, B, alpha_kl, lr, eps, clip, weight_decay, world, use_graph,
+                                            wd_overrides, grad_weight, next_rows, plan_key, have_cur, do_next)
+        finally:
+            self._pf_flags = (False, False)
+
+    def _train_step_planned(self, row_ids, cond, B, alpha_kl, lr, eps, clip, weight_decay, world, use_graph,
+                            wd_overrides, grad_weight, next_rows, plan_key, have_cur, do_next):
+        pf_stage = (next_rows, self._rows_next, B) if do_next else None
         key = plan_key()
         plans = self._plans
         g = plans.get(key)
@@ -1839,23 +1890,55 @@ class CVAEEngine:
                 and cond.is_cuda and row_ids.is_contiguous() and cond.is_contiguous()
                 and row_ids.numel() == B and cond.numel() == B)
         if fast:        # scalars + minibatch staging in one launch
-            self.begin_step(alpha_kl, lr, eps, clip, stage=(row_ids, g["rows"], cond, g["cond"], B))
+            self.begin_step(alpha_kl, lr, eps, clip, stage=(row_ids, g["rows"], cond, g["cond"], B), stage_next=pf_stage)
         else:
             self.begin_step(alpha_kl, lr, eps, clip)
             if g is None:
                 g = (self._capture if use_graph is True else self._record)(B, weight_decay, wd_overrides, world > 1)
                 # buffers allocated lazily during the warm-up pass bump the workspace generation (and drop the old
                 # plans): file the new plan under the generation it was recorded against
+                self._pf_flags = (have_cur, do_next)
                 self._plans[plan_key()] = g
             g["rows"].copy_(row_ids, non_blocking=True)
             g["cond"].copy_(cond, non_blocking=True)
+            if do_next:
+                self._rows_next[:B].copy_(next_rows, non_blocking=True)
+            if have_cur:
+                # recording executes the step - trailing gather included - with placeholder rows: put this
+                # minibatch back into ws["x"] (the replay below does not gather it)
+                ip, ix, dv = self.csr
+                _lib.check(self.lib._lib.sca_csr_gather_rows(
+                    ip.data_ptr(), ix.data_ptr(), dv.data_ptr(), g["rows"].data_ptr(), B, self.G,
+                    0 if self.recon == "mse" else 1, self.ws["x"].data_ptr(), self.G, self.ws["sf"].data_ptr(),
+                    torch.cuda.current_stream(self.device).cuda_stream), "csr_gather")
         if use_graph is True:
             g["fwd"].replay()
         else:
             self._replay(g["fwd"])
+        # what ws["x"] holds once this step's launches have run: the next minibatch, or nothing to rely on
+        self._pf = (dict(rows=next_rows, ptr=next_rows.data_ptr(), version=next_rows._version, B=B, gen=self._ws_gen,
+                         csr=self.csr[0].data_ptr()) if do_next else None)
         if world > 1:
             self._allreduce_and_adam(world, grad_weight, weight_decay, wd_overrides)
         return self.losses
+
+    def _pf_possible(self, next_rows, B):
+        """The trailing gather exists in the fused trVAE step with overlap on (its place in the stream schedule is
+        _fused_path's): everything else keeps the in-line gather at the head of the step."""
+        return (self.overlap and self.use_fused_mid and not (self.use_mmd and self.mmd_on != "z") and self.csr is not None
+                and self.arch != "expimap" and not self.cond_embed
+                and next_rows.is_cuda and next_rows.dtype == torch.int64 and next_rows.is_contiguous()
+                and next_rows.numel() == B and os.environ.get("SCA_PREFETCH", "1") == "1")
+
+    def _pf_matches(self, row_ids, B):
+        """True when ws["x"] / ws["sf"] already hold this minibatch: the previous train_step gathered `next_rows` and
+        `row_ids` is that tensor's storage, unmodified since (the engine holds a reference to it, so the address cannot
+        have been re-used by another tensor; in-place writes bump the shared version counter)."""
+        pf = self._pf
+        return (pf is not None and pf["B"] == B and pf["gen"] == self._ws_gen and self.csr is not None
+                and pf["csr"] == self.csr[0].data_ptr() and row_ids.dtype == torch.int64
+                and row_ids.data_ptr() == pf["ptr"] and row_ids.numel() == B and row_ids.is_contiguous()
+                and row_ids._version == pf["version"] and pf["rows"]._version == pf["version"])
 
     def _allreduce_and_adam(self, world, grad_weight, weight_decay, wd_overrides):
         """Data-parallel end of a step: ONE all-reduce of the flat gradient buffer and the replicated Adam update, both
@@ -1949,7 +2032,7 @@ class CVAEEngine:
         self._restore(snap)
         return out
 
-    def begin_step(self, alpha_kl, lr, eps=0.01, clip=0.0, stage=None):
+    def begin_step(self, alpha_kl, lr, eps=0.01, clip=0.0, stage=None, stage_next=None):
         """Per-step scalars -> device (`hyper`), Philox step counter += 1: one tiny kernel, no host staging.
         `stage` = (rows_src, rows_dst, cond_src, cond_dst, B) also copies the minibatch into the static buffers of
         a recorded plan / graph in the same launch."""
@@ -1960,10 +2043,11 @@ class CVAEEngine:
         st = torch.cuda.current_stream(self.device).cuda_stream
         if stage is not None:
             rs, rd, cs, cd, B = stage
-            _lib.check(self.lib._lib.sca_begin_step_batch(
+            ns, nd, Bn = stage_next if stage_next is not None else (None, None, 0)
+            _lib.check(self.lib._lib.sca_begin_step_batch_next(
                 self.hyper.data_ptr(), self.step_ctr.data_ptr(), float(alpha_kl), float(lr), float(h[2]),
                 float(h[3]), float(eps), float(clip), rs.data_ptr(), rd.data_ptr(), cs.data_ptr(), cd.data_ptr(),
-                int(B), st), "begin_step_batch")
+                int(B), _lib.ptr(ns), _lib.ptr(nd), int(Bn), st), "begin_step_batch")
             return
         _lib.check(self.lib._lib.sca_begin_step(self.hyper.data_ptr(), self.step_ctr.data_ptr(), float(alpha_kl),
                                                 float(lr), float(h[2]), float(h[3]), float(eps), float(clip), st),
@@ -1973,6 +2057,7 @@ class CVAEEngine:
     def encode(self, row_ids, cond, B, mean=True, x_dense=None, eps=None, covs=None):
         """Eval-mode encoder pass: returns (z or mean [B,Z], mean, var) device tensors (views of the workspace)."""
         L, P = self.lib, self.p
+        self._pf = None         # ws["x"] is about to be overwritten
         self._ensure(B)
         eps = self._eps_or_zero(eps, B)
         ws = self.ws

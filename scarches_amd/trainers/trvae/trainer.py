@@ -185,8 +185,13 @@ class Trainer:
                 self.on_epoch_begin(lr, eps)
                 self.engine.bind_csr(tr["indptr"], tr["indices"], tr["data"])
                 self.engine.accum.zero_()
-                for self.iter, batch_data in enumerate(self._epoch_batches()):
+                # one minibatch of look-ahead: the engine gathers minibatch i + 1 beside the tail of step i
+                batches = iter(self._epoch_batches())
+                batch_data, i = next(batches, None), 0
+                while batch_data is not None:
+                    self.iter, self._next_batch = i, next(batches, None)
                     self.on_iteration(batch_data)
+                    batch_data, i = self._next_batch, i + 1
                 self.on_epoch_end()
                 if self.use_early_stopping and not self.check_early_stop():
                     break
@@ -247,8 +252,10 @@ class Trainer:
             sdist.allreduce_mean_(eng.flat_g, self.world, weight=0.0)
             eng.adam_step(weight_decay=self.weight_decay)
             return
+        nxt = getattr(self, "_next_batch", None)
         self.current_loss = eng.train_step(rows, cond, rows.numel(), weight_decay=self.weight_decay,
                                            world=self.world, use_graph=self.launch_mode,
+                                           next_rows=nxt[0] if nxt is not None and nxt[0].numel() == rows.numel() else None,
                                            grad_weight=rows.numel() / n_global if self.world > 1 else None,
                                            n_global=n_global if self.world > 1 else None, **kw)
 

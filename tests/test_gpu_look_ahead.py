@@ -1,0 +1,120 @@
+"""The loader running one minibatch ahead (`CVAEEngine.train_step(next_rows=...)`: the CSR gather of minibatch i + 1 is
+issued at the end of step i, beside the gradient tail and Adam) must give the trajectory of the un-pipelined sequence:
+same gather kernel, same inputs, same arithmetic - only its place in the stream schedule moves.  Checked per launch
+mode (recorded plan at 8192 and 1024 cells; HIP graphs keep the in-step gather, the argument is then ignored), over
+several distinct minibatches, including
+
+  * a promise that is not kept (the next call trains on other rows than announced): the step must gather them itself;
+  * an announced tensor that is modified in place before it is used: detected through its version counter;
+  * a ragged last minibatch (different size: no look-ahead into it) and a get_latent-style encode() between two steps
+    (it overwrites the dense input buffer).
+Tolerance: rel 1e-5 on losses and parameters (float atomics in the likelihood's theta / bias columns may reorder between
+two runs of the SAME sequence; everything else is bit-identical)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G, C, Z, H = 2000, 20, 10, [128, 128]
+N = 60_000
+
+
+@pytest.fixture(scope="module")
+def data():
+    from scarches_amd.synth import make_synthetic_csr
+    dev = torch.device("cuda", 0)
+    indptr, indices, vals, cond_all, _ = make_synthetic_csr(N, G, C, dev, seed=91)
+    return dict(csr=(indptr, indices, vals), cond_all=cond_all)
+
+
+def batches(data, B, n, seed, last=None):
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    out = []
+    for i in range(n):
+        b = B if (last is None or i < n - 1) else last
+        rows = torch.randperm(N, generator=gen, device="cuda")[:b]
+        cond = data["cond_all"][rows]
+        order = torch.argsort(cond, stable=True)
+        out.append((rows[order].contiguous(), cond[order].contiguous().to(torch.int32)))
+    return out
+
+
+def make_engine(data):
+    from bench import build_trvae_params
+    from scarches_amd.engine import CVAEEngine
+    spec = dict(G=G, C=C, H=H, Z=Z, recon="nb", use_bn=False, use_ln=True, use_mmd=True, mmd_on="z", boundary=None,
+                beta=1.0, dr_rate=0.05, seed=2020)
+    eng = CVAEEngine(spec, build_trvae_params(G, C, H, Z), "cuda:0")
+    eng.bind_csr(*data["csr"])
+    return eng
+
+
+def run(data, bs, mode, ahead, hook=None):
+    eng = make_engine(data)
+    losses = []
+    for i, (rows, cond) in enumerate(bs):
+        nxt = bs[i + 1][0] if (ahead and i + 1 < len(bs)) else None
+        if hook is not None:
+            rows, cond, nxt = hook(eng, i, rows, cond, nxt)
+        eng.train_step(rows, cond, rows.numel(), 0.5, 1e-3, use_graph=mode, next_rows=nxt)
+        losses.append(eng.losses.cpu().numpy().copy())
+    torch.cuda.synchronize()
+    return np.array(losses), eng.flat_p.detach().clone(), eng
+
+
+def assert_same(a, b):
+    assert np.all(np.abs(a[0][:, :3] - b[0][:, :3]) <= 1e-5 * np.abs(b[0][:, :3])), (a[0], b[0])
+    assert float((a[1] - b[1]).abs().max()) <= 1e-5 * float(b[1].abs().max())
+
+
+@pytest.mark.parametrize("B,mode", [(8192, "plan"), (1024, True), (1024, "plan")])
+def test_look_ahead_gives_the_same_trajectory(data, B, mode):
+    bs = batches(data, B, 6, seed=3)
+    ref = run(data, bs, mode, ahead=False)
+    got = run(data, bs, mode, ahead=True)
+    assert_same(got, ref)
+    assert got[2]._pf is None                       # the last step announced nothing
+    # the look-ahead was really taken: a plan without the head gather and with the trailing one exists
+    assert any(k[-1] == (True, True) for k in got[2]._plans) == (mode == "plan"), [k[-1] for k in got[2]._plans]
+
+
+def test_broken_promise_and_in_place_edit(data):
+    B = 2048
+    bs = batches(data, B, 6, seed=4)
+    other = batches(data, B, 2, seed=99)
+    keep = {}
+
+    def hook(eng, i, rows, cond, nxt):
+        if i == 1:                                  # announce rows that the next call will not train on
+            nxt = other[0][0]
+        if i == 3:                                  # announce a tensor ...
+            keep["t"] = bs[4][0].clone()
+            nxt = keep["t"]
+        if i == 4:                                  # ... and change it in place before it is used
+            keep["t"].copy_(other[1][0])
+            rows, cond = keep["t"], other[1][1]
+        return rows, cond, nxt
+
+    def hook_ref(eng, i, rows, cond, nxt):
+        return (other[1][0], other[1][1], None) if i == 4 else (rows, cond, None)
+
+    ref = run(data, bs, "plan", ahead=False, hook=hook_ref)
+    got = run(data, bs, "plan", ahead=True, hook=hook)
+    assert_same(got, ref)
+
+
+def test_ragged_last_minibatch_and_encode_between_steps(data):
+    B = 4096
+    bs = batches(data, B, 5, seed=5, last=1000)
+    probe = batches(data, 512, 1, seed=6)[0]
+
+    def hook(eng, i, rows, cond, nxt):
+        if i == 2:                                   # get_latent between two steps overwrites the dense input buffer
+            eng.encode(probe[0], probe[1], 512)
+        return rows, cond, nxt
+
+    ref = run(data, bs, "auto", ahead=False, hook=hook)
+    got = run(data, bs, "auto", ahead=True, hook=hook)
+    assert_same(got, ref)
