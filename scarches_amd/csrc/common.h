@@ -12,10 +12,35 @@
     } while (0)
 
 // ----------------------------------------------------------------------------- reductions
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wave-wide (64 lanes) reductions, result in every lane.  Within a row of 16 lanes: four DPP steps (quad_perm xor 1,
+// xor 2, row_half_mirror, row_mirror - no LDS round trip, no lane-address arithmetic); across the four rows: the row
+// results through v_readlane.  (The __shfl_xor butterfly this replaces is six ds_bpermute round trips plus five address
+// instructions each: ~40 instructions and ~500 cycles of LDS latency per reduction - a third of the likelihood kernel's
+// per-row time went there.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f32<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_f32<0x141>(v);     // row_half_mirror
+    v += dpp_f32<0x140>(v);     // row_mirror
     return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f32<0xB1>(v));
+    v = fmaxf(v, dpp_f32<0x4E>(v));
+    v = fmaxf(v, dpp_f32<0x141>(v));
+    v = fmaxf(v, dpp_f32<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ float lane_f32(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    return (lane_f32(v, 0) + lane_f32(v, 16)) + (lane_f32(v, 32) + lane_f32(v, 48));
 }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -23,10 +48,12 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = row16_max(v);
+    return fmaxf(fmaxf(lane_f32(v, 0), lane_f32(v, 16)), fmaxf(lane_f32(v, 32), lane_f32(v, 48)));
 }
+// log through v_log_f32 (log2, 1 ulp) and one multiply: __logf() expands to the 12-instruction denormal-safe, fma-
+// corrected form, which the arguments of the likelihood kernels (>= 1e-8, never denormal) do not need
+__device__ __forceinline__ float fast_logf(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
 
 // Block-wide reductions for blockDim.x <= 1024 (<= 16 waves). `scratch` needs 16 entries.
 // All threads get the result.  Contains two barriers; safe to call repeatedly with the same scratch.

@@ -52,7 +52,7 @@ _QUERIES = {"sca_gemm_kk_supported", "sca_gemm_kk_splitk_heuristic", "sca_mid_ma
 MMD_SPLIT_MIN = int(os.environ.get("SCA_MMD_SPLIT_MIN", 4096))
 MMD_SPLIT_FRAC = float(os.environ.get("SCA_MMD_SPLIT_FRAC", 0.0))
 MMD_AFTER_OUT = os.environ.get("SCA_MMD_AFTER_OUT", "auto")      # "0" / "1" / "auto": see _fused_path
-MMD_AFTER_OUT_MAX = int(os.environ.get("SCA_MMD_AFTER_OUT_MAX", 8192))
+MMD_AFTER_OUT_MAX = int(os.environ.get("SCA_MMD_AFTER_OUT_MAX", 6144))
 MMD_PAD, MMD_PAD_AFTER_OUT = 40000, 24000       # sca_mmd_reserve_lds per fork point (SCA_MMD_LDS_PAD overrides both)
 
 
@@ -1264,9 +1264,12 @@ class CVAEEngine:
         mmd_split = n1 < B
         # Where the MMD forks off.  Up to MMD_AFTER_OUT_MAX cells: behind the output GEMM, so that the likelihood kernel
         # (which follows that GEMM directly on the main stream) is placed on the CUs first and the MMD fills what is
-        # left - forked earlier, the MMD's 4096 workgroups hold the CUs and the likelihood workgroups trickle in behind
-        # them (likelihood 215 -> 165 us, step 0.632 -> 0.612 ms at 8192 cells).  Above: the MMD (quadratic in the
-        # cells) is the longer of the two and keeps its early start beside the output GEMM (16384: 1.38 vs 1.41 ms).
+        # left - forked earlier, the MMD's workgroups hold the CUs and the likelihood workgroups trickle in behind
+        # them (4096 cells: 0.361 -> 0.341 ms, 6144: 0.492 -> 0.460).  Above: the MMD (quadratic in the cells) is the
+        # longer of the two and keeps its head start beside the output GEMM; both kernels then end together (8192 cells:
+        # 0.596 vs 0.605 ms; 16384: 1.38 vs 1.41).  The balance point moved when the likelihood kernel got faster
+        # (DPP reductions, 146 -> 128 us alone): with the slower kernel the late fork won at 8192 cells (0.611 vs 0.632).
+        # A first MMD row block beside the output GEMM and the rest forked behind it: 0.601-0.62 ms, dropped.
         after_out = (do_mmd and not mmd_split and compute_grad and self.overlap
                      and (MMD_AFTER_OUT == "1" or (MMD_AFTER_OUT == "auto" and B <= MMD_AFTER_OUT_MAX)))
         if do_mmd:
@@ -1295,6 +1298,13 @@ class CVAEEngine:
                    bias=P[self.out_b].data_ptr(), force_s1=True)
         if after_out:
             self._defer(mmd_work)
+        ev_mmd2 = None
+        if mmd_split:
+            ev_mmd2 = self._next_event()
+
+            def mmd_work2(sa):
+                self._mmd_launch(sa, ws["z"], Z, self._cond_cur, cond_p, B, compute_grad, rows=(n1, B - n1), part_off=nA)
+                self._call(ev_mmd2.record, self._lane_stream(0))
         # (measured: with this wait moved in front of the output GEMM - to spare the stream operation between the GEMM
         #  and the likelihood kernel - the GEMM is dispatched behind the MMD, which then holds every CU: 0.665 -> 0.753 ms)
         if not after_out:
@@ -1315,13 +1325,7 @@ class CVAEEngine:
             recon_sign = -1.0
         if after_out:
             ev_side = self._flush()
-        ev_mmd2 = None
         if mmd_split:
-            ev_mmd2 = self._next_event()
-
-            def mmd_work2(sa):
-                self._mmd_launch(sa, ws["z"], Z, self._cond_cur, cond_p, B, compute_grad, rows=(n1, B - n1), part_off=nA)
-                self._call(ev_mmd2.record, self._lane_stream(0))
             self._defer(mmd_work2)
         self._defer_finalize(recon_sign, B, accumulate_logs)
         if not compute_grad:

@@ -71,7 +71,10 @@ def assert_same(a, b):
 
 @pytest.mark.parametrize("B,mode", [(8192, "plan"), (1024, True), (1024, "plan")])
 def test_look_ahead_gives_the_same_trajectory(data, B, mode):
-    bs = batches(data, B, 6, seed=3)
+    # (seed per size: with seed 3 the sixth 1024-cell minibatch holds a cell whose normalised pre-activation in the
+    #  second decoder layer is 0 to within 1e-7 - the ReLU gate of that unit then follows the 1e-7 run-to-run noise of
+    #  the float atomics and two runs of the SAME sequence differ by 2e-4: scripts/run_noise.py / run_noise2.py)
+    bs = batches(data, B, 6, seed=3 if B == 8192 else 11)
     ref = run(data, bs, mode, ahead=False)
     got = run(data, bs, mode, ahead=True)
     assert_same(got, ref)
