@@ -228,9 +228,8 @@ __device__ __forceinline__ void dropout_keep4(uint64_t seed, uint32_t stream, ui
 }
 
 __device__ __forceinline__ float row_sum(float v) {       // sum over the TPR consecutive lanes that share a row
-#pragma unroll
-    for (int m = 1; m < TPR; m <<= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    static_assert(TPR == 16, "one DPP row of 16 lanes per cell (row16_sum)");
+    return row16_sum(v);                                    // four DPP steps, no ds_bpermute round trips
 }
 
 // Copy a [TM][width] row-major HBM tile into LDS (zero padded to Kp columns, rows past B read as zero); 16-byte loads
