@@ -1306,7 +1306,8 @@ class CVAEEngine:
                 self._mmd_launch(sa, ws["z"], Z, self._cond_cur, cond_p, B, compute_grad, rows=(n1, B - n1), part_off=nA)
                 self._call(ev_mmd2.record, self._lane_stream(0))
         # (measured: with this wait moved in front of the output GEMM - to spare the stream operation between the GEMM
-        #  and the likelihood kernel - the GEMM is dispatched behind the MMD, which then holds every CU: 0.665 -> 0.753 ms)
+        #  and the likelihood kernel - the GEMM is dispatched behind the MMD, which then holds every CU: 0.665 -> 0.753 ms;
+        #  in front of the MMD's fork event, so that the MMD is not ahead of the GEMM: +4 us, twice)
         if not after_out:
             self._wait(self._ev_pro)
         rpb = _recon_rows_per_block(B)

@@ -398,6 +398,64 @@ def test_adam_kernel(lib):
     assert (pd_.cpu() - pr).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("B,Bn", [(1000, 1000), (7, 300), (513, 0), (0, 5)])
+def test_begin_step_batch_next_stages_scalars_and_both_minibatches(lib, B, Bn):
+    """sca_begin_step_batch_next: hyper[0..5] <- the step's scalars, step_ctr += 1, rows / conditions of this minibatch
+    and the row ids of the next one copied to their static buffers (bit-exact; B_next = 0 = sca_begin_step_batch)."""
+    from scarches_amd import _lib
+    g0 = torch.Generator().manual_seed(7)
+    rows = dev(torch.randint(0, 1 << 40, (max(B, 1),), generator=g0, dtype=torch.int64))
+    cond = dev(torch.randint(0, 100, (max(B, 1),), generator=g0, dtype=torch.int32))
+    nxt = dev(torch.randint(0, 1 << 40, (max(Bn, 1),), generator=g0, dtype=torch.int64))
+    rows_d, cond_d = dev(torch.full((max(B, 1) + 3,), -1, dtype=torch.int64)), dev(torch.full((max(B, 1) + 3,), -1, dtype=torch.int32))
+    nxt_d = dev(torch.full((max(Bn, 1) + 3,), -1, dtype=torch.int64))
+    hyper, ctr = dev(torch.zeros(8)), dev(torch.tensor([41], dtype=torch.int32))
+    _lib.check(lib.sca_begin_step_batch_next(hyper.data_ptr(), ctr.data_ptr(), 0.25, 2e-3, 0.19, 0.0447, 0.01, 1.5,
+                                             rows.data_ptr(), rows_d.data_ptr(), cond.data_ptr(), cond_d.data_ptr(), B,
+                                             nxt.data_ptr() if Bn else None, nxt_d.data_ptr() if Bn else None, Bn, st()),
+               "begin_step_batch_next")
+    torch.cuda.synchronize()
+    assert np.allclose(hyper.cpu().numpy()[:6], np.float32([0.25, 2e-3, 0.19, 0.0447, 0.01, 1.5]), rtol=0, atol=0)
+    assert int(ctr.cpu()[0]) == 42
+    assert torch.equal(rows_d[:B], rows[:B]) and bool((rows_d[B:] == -1).all())
+    assert torch.equal(cond_d[:B], cond[:B]) and bool((cond_d[B:] == -1).all())
+    assert torch.equal(nxt_d[:Bn], nxt[:Bn]) and bool((nxt_d[Bn:] == -1).all())
+    # a next minibatch without buffers, negative sizes: rejected before any launch
+    assert lib.sca_begin_step_batch_next(hyper.data_ptr(), ctr.data_ptr(), 0.25, 2e-3, 0.19, 0.0447, 0.01, 1.5,
+                                         rows.data_ptr(), rows_d.data_ptr(), cond.data_ptr(), cond_d.data_ptr(), B,
+                                         None, None, 4, st()) == -1
+    assert lib.sca_begin_step_batch_next(hyper.data_ptr(), ctr.data_ptr(), 0.25, 2e-3, 0.19, 0.0447, 0.01, 1.5,
+                                         rows.data_ptr(), rows_d.data_ptr(), cond.data_ptr(), cond_d.data_ptr(), -1,
+                                         None, None, 0, st()) == -1
+
+
+def test_mmd_reserve_lds_is_a_scheduling_knob_only(lib):
+    """sca_mmd_reserve_lds: sizes outside [0, 65536] are rejected; the row-block MMD gives bit-identical losses and
+    gradients whatever the reservation (it only caps the kernel's workgroups per CU)."""
+    from scarches_amd import _lib
+    assert lib.sca_mmd_reserve_lds(-1) == -1 and lib.sca_mmd_reserve_lds(65537) == -1
+    B, D, C = 1500, 10, 6
+    g0 = torch.Generator().manual_seed(3)
+    z = dev(torch.randn(B, D, generator=g0))
+    cond = dev(torch.sort(torch.randint(0, C, (B,), generator=g0)).values.to(torch.int32))
+    outs = []
+    try:
+        for pad in (0, 24000, 40000, 65536):
+            assert lib.sca_mmd_reserve_lds(pad) == 0
+            Wt, cnt = dev(torch.zeros(C * C)), dev(torch.zeros(C, dtype=torch.int32))
+            ns, npart = lib.sca_mmd_rows_num_slabs(B, B, D), lib.sca_mmd_rows_num_partials(B, B, D)
+            part, slabs = dev(torch.zeros(npart, dtype=torch.float64)), dev(torch.zeros(ns * B * D))
+            _lib.check(lib.sca_mmd_rows_fwd_bwd(z.data_ptr(), D, cond.data_ptr(), B, D, C, -1, 1.0, Wt.data_ptr(),
+                                                cnt.data_ptr(), 0, B, part.data_ptr(), slabs.data_ptr(), B * D, st()),
+                       "mmd_rows")
+            torch.cuda.synchronize()
+            outs.append((part.clone(), slabs.clone()))
+    finally:
+        lib.sca_mmd_reserve_lds(40000)
+    for part, slabs in outs[1:]:
+        assert torch.equal(part, outs[0][0]) and torch.equal(slabs, outs[0][1])
+
+
 @pytest.mark.parametrize("Z", [10, 256, 280, 513])
 def test_latent_fwd_narrow_and_wide_rows(Z):
     """sca_latent_fwd against the reference formulas in torch (models/base/_base.py:391-407 sampling,
