@@ -285,7 +285,7 @@ def main():
             # gradient tail (--no-prefetch: gather of minibatch i at the head of the step instead); see --launch
             eng.train_step(ids[i], cs[i], Bx, alpha_kl=0.5, lr=1e-3, eps=0.01, clip=0.0, weight_decay=0.04,
                            world=world, use_graph={"auto": "auto", "plan": "plan", "graph": True, "eager": False}[a.launch],
-                           next_rows=None if a.no_prefetch else ids[i + 1])
+                           next_rows=None if (a.no_prefetch or run.in_step_loader) else ids[i + 1])
         for i in range(warmup):
             one(i)
         if world > 1:
@@ -305,8 +305,16 @@ def main():
             dt = t.item()
         return dt
 
+    run.in_step_loader = False
     dt = run(B, a.steps, a.warmup)
     host_issue_ms = run.host_issue_s / a.steps * 1e3
+    dt_in_step = None
+    if not a.no_prefetch and world == 1:
+        # the same steps with every minibatch gathered at the head of its own step (no look-ahead): reported beside
+        # the headline so that the loader's share is visible in the line itself
+        run.in_step_loader = True
+        dt_in_step = run(B, a.steps, a.warmup)
+        run.in_step_loader = False
     value = B * world * a.steps / dt
     losses = eng.losses.tolist()
     extra = {}
@@ -335,6 +343,10 @@ def main():
         "final_losses": {"recon": losses[0], "kl": losses[1], "mmd": losses[2]},
         "host_issue_ms_per_step": host_issue_ms,
     }
+    if dt_in_step is not None:
+        out["in_step_loader"] = {"ms_per_step": dt_in_step / a.steps * 1e3, "value": B * a.steps / dt_in_step,
+                                 "note": "same steps, CSR gather at the head of each step instead of beside the "
+                                         "previous step's gradient tail"}
     if extra:
         out["extra"] = extra
 
