@@ -182,6 +182,14 @@ __device__ __forceinline__ void tile_gemm(const float* __restrict__ act, int lda
                     bv[s][0] = bp[4 * s * MS_LD];
                     bv[s][1] = bp[4 * s * MS_LD + 16];
                 }
+                // every fragment read issued before the first MFMA: left alone, hipcc interleaves them - read, wait for
+                // the LDS round trip, two MFMAs, read, ... - and the 16 MFMAs of a chunk take 1250 cycles instead of 512
+                static_assert(KC == 32, "the pin below names the 24 fragment registers of a 32-deep chunk");
+                asm volatile("" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(av[4]), "+v"(av[5]), "+v"(av[6]),
+                                  "+v"(av[7]), "+v"(bv[0][0]), "+v"(bv[0][1]), "+v"(bv[1][0]), "+v"(bv[1][1]), "+v"(bv[2][0]),
+                                  "+v"(bv[2][1]), "+v"(bv[3][0]), "+v"(bv[3][1]), "+v"(bv[4][0]), "+v"(bv[4][1]),
+                                  "+v"(bv[5][0]), "+v"(bv[5][1]), "+v"(bv[6][0]), "+v"(bv[6][1]), "+v"(bv[7][0]),
+                                  "+v"(bv[7][1]));
 #pragma unroll
                 for (int s = 0; s < KC / 4; ++s) {
                     acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[s][0], acc[0], 0, 0, 0);
