@@ -42,7 +42,11 @@ for B in (128, 4096, 16384):
         eng.bind_csr(indptr, indices, data)
         ids, cs = epoch_batches(cond_all, 2, B, gen)
         eng.begin_step(0.5, 1e-3)
-        eng.forward_backward(ids[0], cs[0], B)
+        import os
+        masks = None
+        if os.environ.get("MID_MASKS") == "1" and p > 0:
+            masks = {ly.mask_key: (torch.rand(B, ly.n_out, device=dev) > p).to(torch.uint8) for ly in eng.enc + eng.dec}
+        eng.forward_backward(ids[0], cs[0], B, masks=masks)
         torch.cuda.synchronize()
         st = torch.cuda.current_stream().cuda_stream
         L = _lib.load()
