@@ -225,7 +225,8 @@ __device__ __forceinline__ void tile_gemm(const float* __restrict__ act, int lda
     __syncthreads();
 }
 
-// act tiles are [TM][ld] with ld = round_up(width, KC) + 1 (conflict-free fragment reads); columns past the layer width must read as zero for the
+// act tiles are [TM][ld] with ld = round_up(width, KC) + 2: the A fragment of lane (l16, kg) sits at l16 * ld + kg, and
+// ld = 2 (mod 32) puts the 32 lanes of a half-wave (kg = 0, 1) on 32 different banks (+1 left them 2-way conflicted); columns past the layer width must read as zero for the
 // K-chunk loop above, so every producer of a tile zero-fills up to the next multiple of KC.
 
 // 4 dropout keep decisions of columns col4 .. col4+3 (col4 % 4 == 0) from ONE Philox call - same bits as dropout_keep.
@@ -742,7 +743,7 @@ int check_and_ld(const sca_mid_args* a, int* ld, size_t* shm, int* wide) {
         if (a->K0 > maxn) maxn = a->K0;
     }
     *wide = maxn > 128;
-    *ld = ((maxw + KC - 1) / KC) * KC + 1;
+    *ld = ((maxw + KC - 1) / KC) * KC + 2;
     *shm = sizeof(float) * ((size_t)2 * TM * (*ld) + (size_t)KC * MS_LD);
     return 0;
 }
