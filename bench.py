@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--latent", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-loader-compare", action="store_true",
+                    help="skip the second timed pass with the in-step loader (profiles of the headline pass only)")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="gather each minibatch at the head of its own step instead of beside the previous step's tail")
     ap.add_argument("--dp-mmd", choices=["local", "exact"], default="local",
@@ -309,7 +311,7 @@ def main():
     dt = run(B, a.steps, a.warmup)
     host_issue_ms = run.host_issue_s / a.steps * 1e3
     dt_in_step = None
-    if not a.no_prefetch and world == 1:
+    if not a.no_prefetch and not a.no_loader_compare and world == 1:
         # the same steps with every minibatch gathered at the head of its own step (no look-ahead): reported beside
         # the headline so that the loader's share is visible in the line itself
         run.in_step_loader = True
