@@ -18,7 +18,8 @@
 extern "C" {
 #endif
 
-/* Library / device sanity: returns the ABI version; fills name[0..len) with the HIP device name (host buffer). */
+/* Library / device sanity: returns the ABI version (3; bumped on every incompatible change of a signature or of the
+ * meaning of an argument - callers assert it after dlopen); fills name[0..len) with the HIP device name (host buffer). */
 int sca_abi_version(void);
 int sca_device_name(char* name, int len);
 
@@ -186,7 +187,8 @@ int sca_mmd_rows_fwd_bwd(const float* feat, int ld, const int32_t* cond, int B, 
 
 /* ---- optimiser / bookkeeping ---------------------------------------------------------------------------------
  * hyper (device, float[8]): [0] alpha_kl  [1] lr  [2] 1-beta1^t  [3] sqrt(1-beta2^t)  [4] adam eps  [5] clip value
- * [6] weight of this minibatch in the epoch-log accumulators (1; n_local / n_global on a data-parallel rank).
+ * [6] weight of this minibatch in the epoch-log accumulators (1; n_local / n_global on a data-parallel rank; 0 reads
+ *     as 1, so a zero-initialised block keeps the un-weighted behaviour).
  * sca_adam_step: torch.optim.Adam semantics (trainers/trvae/trainer.py:221-223, clip: :277-278) on a flat range.
  * sca_finalize_losses: losses[0..3] = recon (= recon_sign * sum(row_recon)/B), kl, mmd, recon + alpha*kl + mmd
  * (trainers/trvae/unsupervised.py:62-70); accum[0..3] += hyper[6] * those, accum[4] += hyper[6] (per-epoch log means
@@ -388,7 +390,11 @@ int sca_knn_vote(const float* dist, const int32_t* idx, int Nq, int k, const int
  * sca_knn_num_chunks(Nr, Nq) * Nq * k <= sca_knn_static_max_entries() (= 2^21; e.g. 32768 queries at k = 50 against
  * any reference size); larger problems return -3 and belong to sca_knn_topk.  The array keeps the previous call's
  * contents; nothing needs clearing (every partial entry that is read is written first).  Calls that overlap on one
- * GPU (different streams) share the array and race: issue them on one stream.  Calls no hipMalloc / hipFree. */
+ * GPU (different streams) share the array and race: issue them on one stream.  Calls no hipMalloc / hipFree.
+ * Warm-up: a call with Nq = 0 (other arguments ignored) resolves this device's address of the array and sets the
+ * kernels' attributes, the only steps that are not stream operations; callers that use the entry point under HIP graph
+ * capture make that call once per device before the capture begins.  The 16 MiB array is part of the code object:
+ * every GPU that loads the library holds it, whether or not this entry point is ever called. */
 long long sca_knn_static_max_entries(void);
 int sca_knn_topk_static(const float* ref, int Nr, const float* qry, int Nq, int D, int k, float* dist, int32_t* idx,
                         void* stream);

@@ -138,6 +138,7 @@ SIGNATURES = {
 RESTYPES = {"sca_hsic_workspace_floats": LL, "sca_proto_workspace_bytes": LL, "sca_knn_static_max_entries": LL}
 
 _lib = None
+ABI_VERSION = 3       # sca_abi_version() of the library this binding was written against
 
 
 class HipLibraryError(RuntimeError):
@@ -171,6 +172,10 @@ def load():
             raise HipLibraryError(f"symbol {name} missing from {LIB_PATH}") from e
         fn.argtypes = argtypes
         fn.restype = RESTYPES.get(name, I)
+    got = lib.sca_abi_version()
+    if got != ABI_VERSION:
+        raise HipLibraryError(f"{LIB_PATH} has ABI version {got}, this package binds version {ABI_VERSION}: rebuild it "
+                              "with `make -C scarches_amd/csrc`")
     _lib = lib
     return lib
 

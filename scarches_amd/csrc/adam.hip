@@ -56,7 +56,8 @@ __global__ __launch_bounds__(256) void finalize_losses_kernel(const float* __res
             // the reference logs float32 `.item()` values per iteration and averages them per epoch
             // hyper[6] = weight of this minibatch's means in the epoch log (1; n_local / n_global on a data-parallel
             // rank, so that the all-reduced sums give the means over the GLOBAL minibatches also for ragged shards)
-            const double w = (double)hyper[6];
+            // (a zero-initialised hyper[8] - valid before the weight existed - reads as weight 1)
+            const double w = hyper[6] == 0.f ? 1.0 : (double)hyper[6];
             accum[0] += w * (double)(float)recon; accum[1] += w * (double)(float)kl; accum[2] += w * (double)(float)mm;
             accum[3] += w * (double)(float)tot; accum[4] += w;
         }

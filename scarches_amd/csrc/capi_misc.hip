@@ -2,7 +2,9 @@
 #include <hip/hip_runtime.h>
 #include <string.h>
 
-extern "C" int sca_abi_version(void) { return 1; }
+// 1: round 1.  2: sca_recon_rows gained row_dsf, sca_mse_rows' relu flag became an activation code, sca_finalize_losses
+// weighs the epoch accumulators by hyper[6].  3: round 3 (hyper[6] == 0 reads as 1; new entry points).
+extern "C" int sca_abi_version(void) { return 3; }
 
 extern "C" int sca_device_name(char* name, int len) {
     int dev = 0;

@@ -230,6 +230,29 @@ extern "C" int sca_knn_num_chunks(int Nr, int Nq) {
     return (int)chunks;
 }
 
+// Once per device, outside any stream capture: the merge / vote kernels' dynamic-LDS limit for the largest k (a
+// hipFuncSetAttribute is not a stream operation and must not run while a stream of the thread captures).
+namespace {
+std::mutex g_knn_init_mu;
+bool g_knn_init_done[64] = {};
+int knn_init_current_device() {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64) return -4;
+    std::lock_guard<std::mutex> lock(g_knn_init_mu);
+    if (!g_knn_init_done[dev]) {
+        const int shm = (int)(sizeof(float) * (size_t)2 * KNN_KMAX * KNN_T);
+        e = hipFuncSetAttribute((const void*)knn_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)knn_vote_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+        if (e != hipSuccess) return (int)e;
+        g_knn_init_done[dev] = true;
+    }
+    return 0;
+}
+}  // namespace
+
 // Shared launcher of the two top-k entry points: scan over reference chunks into the partial lists, then merge.
 static int knn_topk_launch(const float* ref, int Nr, const float* qry, int Nq, int D, int k, float* pd2,
                            int32_t* pidx, float* dist, int32_t* idx, hipStream_t st) {
@@ -246,7 +269,6 @@ static int knn_topk_launch(const float* ref, int Nr, const float* qry, int Nq, i
     else KNN_SCAN(64, 1);
 #undef KNN_SCAN
     const size_t shm2 = sizeof(float) * (size_t)2 * k * KNN_T;
-    hipFuncSetAttribute((const void*)knn_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
     hipLaunchKernelGGL(knn_merge_kernel, dim3((Nq + KNN_T - 1) / KNN_T), dim3(KNN_T), shm2, st, pd2, pidx, Nq, k, ny,
                        dist, idx);
     SCA_CHECK_LAUNCH();
@@ -258,6 +280,7 @@ extern "C" int sca_knn_topk(const float* ref, int Nr, const float* qry, int Nq, 
     if (Nq <= 0) return 0;
     if (Nr <= 0 || D <= 0 || k <= 0) return -1;
     if (k > KNN_KMAX || k > Nr || D > 64) return -2;
+    if (const int rc = knn_init_current_device()) return rc;
     return knn_topk_launch(ref, Nr, qry, Nq, D, k, pd2, pidx, dist, idx, (hipStream_t)stream);
 }
 
@@ -299,9 +322,17 @@ extern "C" long long sca_knn_static_max_entries(void) { return SCA_KNN_STATIC_EN
 
 extern "C" int sca_knn_topk_static(const float* ref, int Nr, const float* qry, int Nq, int D, int k, float* dist,
                                    int32_t* idx, void* stream) {
-    if (Nq <= 0) return 0;
+    if (Nq <= 0) {
+        // WARM-UP call (Nq = 0, other arguments ignored): resolves this device's address of the static array and sets
+        // the kernels' attributes - the two things below that are not stream operations.  A caller that will use the
+        // entry point under HIP graph capture makes this call once per device BEFORE capturing.
+        unsigned char* base = nullptr;
+        if (const int rc = knn_init_current_device()) return rc;
+        return knn_scratch_for_current_device(&base);
+    }
     if (Nr <= 0 || D <= 0 || k <= 0) return -1;
     if (k > KNN_KMAX || k > Nr || D > 64) return -2;
+    if (const int rc0 = knn_init_current_device()) return rc0;
     const long long entries = (long long)sca_knn_num_chunks(Nr, Nq) * Nq * k;
     if (entries > SCA_KNN_STATIC_ENTRIES) return -3;          // beyond the static workspace: use sca_knn_topk
     unsigned char* base = nullptr;
@@ -316,8 +347,8 @@ extern "C" int sca_knn_vote(const float* dist, const int32_t* idx, int Nq, int k
                             double* prob, void* stream) {
     if (Nq <= 0) return 0;
     if (k <= 0 || k > KNN_KMAX) return -2;
+    if (const int rc = knn_init_current_device()) return rc;
     const size_t shm = sizeof(float) * (size_t)2 * k * KNN_T;
-    hipFuncSetAttribute((const void*)knn_vote_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     hipLaunchKernelGGL(knn_vote_kernel, dim3((Nq + KNN_T - 1) / KNN_T), dim3(KNN_T), shm, (hipStream_t)stream, dist, idx,
                        Nq, k, labels, pred, prob);
     SCA_CHECK_LAUNCH();

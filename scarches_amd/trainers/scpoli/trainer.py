@@ -113,8 +113,14 @@ class scPoliTrainer(Trainer):
         if self.world > 1:
             # the reference's split shuffles with the unseeded global numpy RNG (trainers/scpoli/_utils.py:140,160);
             # data-parallel ranks must build the SAME split, so they seed it alike
+            # - and hand the global RNG back as they found it (the single-process path never touches it)
+            rng_state = np.random.get_state()
             np.random.seed(self.seed)
-        self.update_labeled_indices(self.labeled_indices)
+        try:
+            self.update_labeled_indices(self.labeled_indices)
+        finally:
+            if self.world > 1:
+                np.random.set_state(rng_state)
         self.prototype_training = prototype_training
         self.unlabeled_prototype_training = unlabeled_prototype_training
         lab_values = self.train_data.labeled_vector.unique().tolist()

@@ -103,11 +103,17 @@ class Trainer:
         if self.world > 1:
             # without a condition key the split shuffles with the unseeded global numpy RNG (trainers/trvae/_utils.py:
             # 128-143); data-parallel ranks must build the SAME split, so they seed it alike
+            # - and hand the global RNG back as they found it (the single-process path never touches it)
+            rng_state = np.random.get_state()
             np.random.seed(self.seed)
-        self.train_data, self.valid_data = make_dataset(
-            self.adata, train_frac=self.train_frac, condition_key=self.condition_key,
-            cell_type_keys=self.cell_type_keys, condition_encoder=self.model.condition_encoder,
-            cell_type_encoder=self.model.cell_type_encoder)
+        try:
+            self.train_data, self.valid_data = make_dataset(
+                self.adata, train_frac=self.train_frac, condition_key=self.condition_key,
+                cell_type_keys=self.cell_type_keys, condition_encoder=self.model.condition_encoder,
+                cell_type_encoder=self.model.cell_type_encoder)
+        finally:
+            if self.world > 1:
+                np.random.set_state(rng_state)
 
     # ------------------------------------------------------------------------------------------ data
     def initialize_loaders(self):

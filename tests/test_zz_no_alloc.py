@@ -59,3 +59,36 @@ def test_knn_topk_static_rejects_sizes_beyond_its_workspace():
     assert rc == -3
     with pytest.raises(_lib.HipLibraryError):
         _lib.check(rc, "knn_topk_static")
+
+
+def test_knn_topk_static_inside_a_graph_capture_after_the_warm_up_call():
+    """The Nq = 0 warm-up call does the two steps that are not stream operations (address lookup, kernel attributes);
+    after it the entry point only launches kernels and can sit inside a HIP graph: replaying the graph on new inputs
+    written into the captured buffers gives sca_knn_topk's result bit for bit."""
+    from scarches_amd import _lib
+    lib = _lib.load()
+    assert lib.sca_knn_topk_static(None, 0, None, 0, 0, 0, None, None, None) == 0       # warm-up, outside capture
+    nr, nq, d, k = 20_000, 1_000, 10, 20
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    ref = torch.randn(nr, d, device="cuda", generator=gen)
+    qry = torch.randn(nq, d, device="cuda", generator=gen)
+    dist = torch.empty(nq, k, device="cuda")
+    idx = torch.empty(nq, k, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        rc = lib.sca_knn_topk_static(ref.data_ptr(), nr, qry.data_ptr(), nq, d, k, dist.data_ptr(), idx.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    qry.copy_(torch.randn(nq, d, device="cuda", generator=gen))     # new queries into the captured buffer
+    g.replay()
+    torch.cuda.synchronize()
+    chunks = lib.sca_knn_num_chunks(nr, nq)
+    pd2 = torch.empty(chunks * nq * k, device="cuda")
+    pidx = torch.empty(chunks * nq * k, dtype=torch.int32, device="cuda")
+    d0 = torch.empty(nq, k, device="cuda")
+    i0 = torch.empty(nq, k, dtype=torch.int32, device="cuda")
+    _lib.check(lib.sca_knn_topk(ref.data_ptr(), nr, qry.data_ptr(), nq, d, k, pd2.data_ptr(), pidx.data_ptr(),
+                                d0.data_ptr(), i0.data_ptr(), None), "knn_topk")
+    torch.cuda.synchronize()
+    assert torch.equal(d0, dist) and torch.equal(i0, idx)
