@@ -362,6 +362,13 @@ int sca_proto_loss(const float* z, int ld, int B, int Z, const float* P, int K, 
                    const uint8_t* labeled, float weight, const float* Pu, int Ku, float weight_u, void* work,
                    double* loss_weighted, float* raw, int accumulate_raw, float* dz, int lddz, float* dPu,
                    void* stream);
+/* sca_proto_classify: scpoli.classify (models/scpoli/scpoli.py:270-315, p = 2) for one hierarchy level.  classes [Kc]
+ * = prototype rows of the level (every entry in [0, K): the caller checks); dists [B][Kc] = euclidean distances
+ * (get_prob = 0) or softmax(-distance) over the level (get_prob = 1); pred [B] = classes[argmin distance] /
+ * classes[argmax probability] (first one on ties, as torch.min / torch.max); uncert [B] = that minimum / maximum.
+ * -2 when Kc * Z floats exceed 48 KB. */
+int sca_proto_classify(const float* z, int ld, int B, int Z, const float* P, int K, const int32_t* classes, int Kc,
+                       int get_prob, float* dists, int32_t* pred, float* uncert, void* stream);
 int sca_class_moments(const float* z, int ld, int N, int Z, const int32_t* labels, int n_levels, const uint8_t* sel,
                       int K, double* cnt, double* sum, double* outer, void* stream);
 int sca_class_moments_finish(const double* cnt, const double* sum, const double* outer, int K, int Z,

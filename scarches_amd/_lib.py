@@ -132,6 +132,7 @@ SIGNATURES = {
     "sca_embed_scatter_add": [P, P, I, I, I, I, P, I, P, P],
     "sca_proto_workspace_bytes": [I, I, I],
     "sca_proto_loss": [P, I, I, I, P, I, P, I, P, F, P, I, F, P, P, P, I, P, I, P, P],
+    "sca_proto_classify": [P, I, I, I, P, I, P, I, I, P, P, P, P],
     "sca_class_moments": [P, I, I, I, P, I, P, I, P, P, P, P],
     "sca_class_moments_finish": [P, P, P, I, I, P, P, P, P, P, P],
 }

@@ -158,6 +158,49 @@ __global__ __launch_bounds__(256) void proto_finish_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------- classify
+// scpoli.classify (models/scpoli/scpoli.py:270-315, p = 2): distances of every latent row to the prototypes of the
+// current hierarchy level (classes [Kc] = rows of P), optionally softmax(-d) over the level, and the row's winner
+// (first minimum distance / first maximum probability, as torch.min / torch.max).  One thread per row; the level's
+// prototypes are staged in LDS.  The same distance arithmetic as the prototype losses (sum of squared differences).
+__global__ __launch_bounds__(256) void proto_classify_kernel(const float* __restrict__ z, int ld, int B, int Z,
+                                                             const float* __restrict__ P,
+                                                             const int32_t* __restrict__ classes, int Kc,
+                                                             int get_prob, float* __restrict__ dists,
+                                                             int32_t* __restrict__ pred, float* __restrict__ uncert) {
+    extern __shared__ float pl[];                 // [Kc][Z]
+    for (int i = threadIdx.x; i < Kc * Z; i += 256) pl[i] = P[(long long)classes[i / Z] * Z + (i % Z)];
+    __syncthreads();
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const float* zb = z + (long long)b * ld;
+    float* db = dists + (long long)b * Kc;
+    float best = INFINITY;
+    int bk = 0;
+    for (int k = 0; k < Kc; ++k) {
+        float d2 = 0.f;
+        for (int q = 0; q < Z; ++q) { const float t = zb[q] - pl[k * Z + q]; d2 = fmaf(t, t, d2); }
+        const float d = sqrtf(d2);
+        db[k] = d;
+        if (d < best) { best = d; bk = k; }
+    }
+    if (get_prob) {
+        // softmax(-d): the largest probability belongs to the smallest distance (first one on ties)
+        float se = 0.f;
+        for (int k = 0; k < Kc; ++k) se += expf(best - db[k]);
+        const float inv = 1.0f / se;
+        float pb = -1.f;
+        for (int k = 0; k < Kc; ++k) {
+            const float pr = expf(best - db[k]) * inv;
+            db[k] = pr;
+            if (pr > pb) { pb = pr; bk = k; }
+        }
+        best = pb;
+    }
+    pred[b] = classes[bk];
+    uncert[b] = best;
+}
+
 // ------------------------------------------------------------------------------------------------- moments
 __global__ __launch_bounds__(256) void class_moments_kernel(const float* __restrict__ z, int ld, int N, int Z,
                                                             const int32_t* __restrict__ labels, int n_levels,
@@ -257,6 +300,19 @@ extern "C" int sca_proto_loss(const float* z, int ld, int B, int Z, const float*
     hipLaunchKernelGGL(proto_grad_kernel, dim3((B + 255) / 256), dim3(256), 0, st, a);
     hipLaunchKernelGGL(proto_finish_kernel, dim3(1), dim3(256), 0, st, rl, ru, B, weight, weight_u, loss_weighted, raw,
                        accumulate_raw);
+    SCA_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int sca_proto_classify(const float* z, int ld, int B, int Z, const float* P, int K,
+                                  const int32_t* classes, int Kc, int get_prob, float* dists, int32_t* pred,
+                                  float* uncert, void* stream) {
+    if (B <= 0) return 0;
+    if (ld < Z || Z <= 0 || Kc <= 0 || K <= 0 || !P || !classes) return -1;
+    const size_t shm = sizeof(float) * (size_t)Kc * Z;
+    if (shm > 48 * 1024) return -2;
+    hipLaunchKernelGGL(proto_classify_kernel, dim3((B + 255) / 256), dim3(256), shm, (hipStream_t)stream, z, ld, B, Z, P,
+                       classes, Kc, get_prob, dists, pred, uncert);
     SCA_CHECK_LAUNCH();
     return 0;
 }

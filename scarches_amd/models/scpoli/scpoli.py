@@ -104,19 +104,40 @@ class scpoli(EngineBackedModule):
         z, mu, var = eng.encode(None, None, x.shape[0], mean=False, x_dense=x, covs=covs)
         return mu.clone() if mean else z.clone()
 
+    def _proto_distances(self, latent, classes_list, get_prob=False):
+        """(classes_list[winner], winner's distance / probability, [n, len(classes_list)] distances or softmax(-d)) of
+        the latent rows against the labeled prototypes of one hierarchy level: sca_proto_classify (scpoli_ops.hip)."""
+        from ... import _lib
+        lib = _lib.load()
+        dev = latent.device
+        if dev.type != "cuda":
+            raise _lib.HipLibraryError("scpoli.classify runs on a HIP device only (no CPU fallback)")
+        protos = self.prototypes_labeled["mean"] = self.prototypes_labeled["mean"].to(dev)
+        P = protos.to(torch.float32).contiguous()
+        cl = classes_list.to(dev).to(torch.int32).contiguous()
+        K = P.shape[0]
+        if cl.numel() == 0 or int(cl.min()) < 0 or int(cl.max()) >= K:
+            raise IndexError("classes_list holds a prototype index outside [0, %d)" % K)
+        lat = latent.to(torch.float32).contiguous()
+        n, Z = lat.shape
+        dists = torch.empty(n, cl.numel(), dtype=torch.float32, device=dev)
+        pred = torch.empty(n, dtype=torch.int32, device=dev)
+        uncert = torch.empty(n, dtype=torch.float32, device=dev)
+        _lib.check(lib.sca_proto_classify(lat.data_ptr(), lat.stride(0) if n else Z, n, Z, P.data_ptr(), K,
+                                          cl.data_ptr(), cl.numel(), int(bool(get_prob)), dists.data_ptr(),
+                                          pred.data_ptr(), uncert.data_ptr(),
+                                          torch.cuda.current_stream(dev).cuda_stream), "proto_classify")
+        return pred.to(classes_list.dtype), uncert, dists
+
     def classify(self, x, c=None, prototype=False, classes_list=None, p=2, get_prob=False, log_distance=True):
         """Nearest labeled prototype (restricted to `classes_list`): returns (preds, uncertainty, distances)."""
+        if p != 2:
+            raise NotImplementedError("classify: only the euclidean distance (p = 2) is built in the HIP path")
         latent = x if prototype else self.get_latent(x, c)
         dev = latent.device
-        protos = self.prototypes_labeled["mean"] = self.prototypes_labeled["mean"].to(dev)
-        classes_list = classes_list.to(dev)
-        dists = torch.cdist(latent, protos[classes_list, :], p)
-        if get_prob:
-            dists = torch.softmax(-dists, dim=1)
-            uncert, preds = torch.max(dists, dim=1)
-        else:
-            uncert, preds = torch.min(dists, dim=1)
-        return classes_list[preds], uncert, dists
+        if dev.type != "cuda":
+            latent = latent.to(next(self.parameters()).device)
+        return self._proto_distances(latent, classes_list.to(latent.device), get_prob)
 
     def add_new_cell_type(self, latent, cell_type_name, prototypes, classes_list=None):
         """Register a new cell type whose prototype is the mean of the given unlabeled prototypes; its covariance is
@@ -130,8 +151,7 @@ class scpoli(EngineBackedModule):
         new_proto = self.prototypes_unlabeled["mean"][prototypes].mean(0).unsqueeze(0)
         self.prototypes_labeled["mean"] = torch.cat((self.prototypes_labeled["mean"], new_proto), dim=0).to(dev)
         latent = latent.to(dev)
-        d = torch.cdist(latent, self.prototypes_labeled["mean"][classes_list.to(dev), :])
-        y_hat = classes_list.to(dev)[torch.min(d, 1)[1]]
+        y_hat, _, _ = self._proto_distances(latent, classes_list.to(dev))
         rows = y_hat.eq(self.n_cell_types - 1).nonzero(as_tuple=False)[:, 0]
         new_cov = cov(latent[rows, :]).unsqueeze(0).to(self.prototypes_labeled["cov"].device)
         self.prototypes_labeled["cov"] = torch.cat((self.prototypes_labeled["cov"], new_cov), dim=0)

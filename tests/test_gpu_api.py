@@ -119,6 +119,81 @@ def test_knn_accuracy_matches_oracle_training(trained):
     assert abs(acc_o - acc_h) <= 0.005 + 1e-9, (acc_o, acc_h)
 
 
+def test_knn_accuracy_paired_replay_of_reference_training_runs():
+    """North-star acceptance, trajectory to trajectory: two training runs of the REAL reference (seeds 0 and 1; 2000
+    cells x 128 genes, 10 epochs = 150 Adam steps; tests/golden/make_goldens_round2.py knn_paired) stored the sampler's
+    minibatch ids (trainers/trvae/trainer.py:154-191), the reparameterisation noise and every dropout keep-mask of
+    every iteration.  The HIP engine replays exactly those draws from the reference's initial weights (same loss
+    composition / annealing / Adam as trainer.py:193-223,262-280): per seed the latent kNN label-transfer accuracy
+    (utils/knn.py-style distance-weighted kNN on the encoder means) must agree within 0.5 points, the final parameters
+    within 1e-3 of each tensor's scale and the latent means within 1e-3 of theirs."""
+    import json
+    import os
+    from collections import OrderedDict
+    from scarches_amd.engine import CVAEEngine
+    from tests._util import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "knn_paired.npz"))
+    cfg = json.loads(str(z["cfg"]))
+    n, G, C, Z, H, bs = cfg["n"], cfg["G"], cfg["C"], cfg["Z"], cfg["H"], cfg["batch_size"]
+    X = sp.csr_matrix((z["x_data"], z["x_indices"], z["x_indptr"]), shape=(n, G))
+    cond, t, a, b = z["cond"], z["cell_type"], z["split_a"], z["split_b"]
+    spec = dict(G=G, C=C, H=H, Z=Z, recon="nb", use_bn=False, use_ln=True, dr_rate=cfg["dr_rate"], use_mmd=True,
+                mmd_on="z", beta=1.0, seed=0)
+    for seed in range(2):
+        pre = f"s{seed}/"
+        W0 = OrderedDict((k[len(pre) + 3:], torch.tensor(z[k])) for k in z.files if k.startswith(pre + "w0/"))
+        W1 = {k[len(pre) + 3:]: z[k] for k in z.files if k.startswith(pre + "w1/")}
+        eng = CVAEEngine(dict(spec), W0, "cuda:0")
+        tr = z[pre + "train_idx"].astype(np.int64)
+        Xt = X[tr].tocsr()
+        Xt.sort_indices()
+        eng.bind_csr(torch.tensor(Xt.indptr.astype(np.int64)).cuda(), torch.tensor(Xt.indices.astype(np.int32)).cuda(),
+                     torch.tensor(Xt.data.astype(np.float32)).cuda())
+        cond_t = torch.tensor(cond[tr].astype(np.int32)).cuda()
+        samples = z[pre + "samples"].astype(np.int64)            # [epochs][n_train] rows of the training subset
+        n_full = samples.shape[1] // bs
+        tail = samples.shape[1] - n_full * bs
+        keys = ("enc0", "enc1", "dec0", "dec1")
+        widths = dict(enc0=H[0], enc1=H[1], dec0=H[1], dec1=H[0])
+        i_full = i_tail = 0
+        for epoch in range(cfg["epochs"]):
+            alpha = min(cfg["alpha_kl"] * epoch / cfg["alpha_epoch_anneal"], cfg["alpha_kl"])
+            for it in range(n_full + (1 if tail else 0)):
+                rows = torch.tensor(samples[epoch, it * bs:(it + 1) * bs]).cuda()
+                B = rows.numel()
+                full = B == bs
+                eps = torch.tensor(z[pre + ("eps_full" if full else "eps_tail")][i_full if full else i_tail]).cuda()
+                masks = {}
+                for k in keys:
+                    bits = z[pre + ("mask_full/" if full else "mask_tail/") + k][i_full if full else i_tail]
+                    masks[k] = torch.tensor(np.unpackbits(bits, axis=1)[:, :widths[k]].copy()).cuda().contiguous()
+                if full:
+                    i_full += 1
+                else:
+                    i_tail += 1
+                eng.begin_step(alpha_kl=alpha, lr=cfg["lr"], eps=cfg["eps"])
+                eng.forward_backward(rows, cond_t[rows].contiguous(), B, train=True, compute_grad=True, eps=eps,
+                                     masks=masks)
+                eng.adam_step(weight_decay=cfg["weight_decay"])
+        torch.cuda.synchronize()
+        assert i_full == z[pre + "eps_full"].shape[0] and i_tail == z[pre + "eps_tail"].shape[0]
+        for k, ref in W1.items():
+            got = eng.p[k].detach().cpu().numpy()
+            assert np.max(np.abs(got - ref)) <= 1e-3 * np.max(np.abs(ref)), (seed, k, np.max(np.abs(got - ref)))
+        Xa = X.tocsr()
+        Xa.sort_indices()
+        eng.bind_csr(torch.tensor(Xa.indptr.astype(np.int64)).cuda(), torch.tensor(Xa.indices.astype(np.int32)).cuda(),
+                     torch.tensor(Xa.data.astype(np.float32)).cuda())
+        _, mu, _ = eng.encode(torch.arange(n, device="cuda"), torch.tensor(cond.astype(np.int32)).cuda(), n, mean=True)
+        zl = mu.cpu().numpy()
+        ref_lat = z[pre + "latent_mean"]
+        assert np.max(np.abs(zl - ref_lat)) <= 1e-3 * np.max(np.abs(ref_lat)), np.max(np.abs(zl - ref_lat))
+        acc, acc_ref = knn_acc(zl[a], t[a], zl[b], t[b]), float(z[pre + "acc"])
+        print("paired kNN acceptance: seed", seed, "reference", round(acc_ref, 4), "hip", round(acc, 4))
+        assert 0.7 < acc_ref < 0.95                               # below the ceiling: the bar can fail
+        assert abs(acc - acc_ref) <= 0.005 + 1e-9, (seed, acc, acc_ref)
+
+
 def test_knn_accuracy_matches_reference_training_below_the_ceiling():
     """The same acceptance on a HARD set (cell types that share 80 % of their profile; accuracy 0.86 - 0.99 from seed to
     seed): five models trained by the REAL reference (tests/golden/make_goldens_round2.py knn; seeds 0-4, the schedule

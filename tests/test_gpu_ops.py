@@ -66,6 +66,57 @@ def test_gemm_modes(lib, M, N, K, mode):
         assert err <= 2e-6 * scale, (S, err, scale)
 
 
+@pytest.mark.parametrize("M", [4, 132, 2000])
+@pytest.mark.parametrize("N", [2, 66, 130])
+@pytest.mark.parametrize("K", [17, 1000, 8192 + 3])
+def test_gemm_kk_shapes(lib, M, N, K):
+    """sca_gemm_kk_f32 (register-direct C = A^T B, both operands k-major) against an fp64 product: clamped lanes
+    (M, N not multiples of the 128 x 64 wave tile), k tails, waves whose k range is empty (K = 17 with 3 x 4 wave
+    ranges), split counts 1 / 3 / heuristic with their slab strides, padded leading dimensions and an output pitch that
+    is not a multiple of 4 (scalar store path)."""
+    from scarches_amd import _lib
+    g = torch.Generator().manual_seed(M * 131 + N * 17 + K)
+    lda, ldb = M + 4, N + 2                        # padded operand pitches (multiples of 4 / 2)
+    A = torch.randn(K, lda, generator=g)
+    Bm = torch.randn(K, ldb, generator=g)
+    ref = A[:, :M].double().t() @ Bm[:, :N].double()
+    scale = (A[:, :M].abs().double().t() @ Bm[:, :N].abs().double()).max().item()
+    Ad, Bd = dev(A), dev(Bm)
+    assert lib.sca_gemm_kk_supported(Ad.data_ptr(), lda, Bd.data_ptr(), ldb, M, N) == 1
+    for S in sorted({1, 3, lib.sca_gemm_kk_splitk_heuristic(M, N, K)}):
+        for ldc in (N, N + 3):                     # N + 3: rows of C that are not 16-byte aligned
+            slabs = torch.full((S, M, ldc), float("nan"), device="cuda")
+            _lib.check(lib.sca_gemm_kk_f32(Ad.data_ptr(), lda, Bd.data_ptr(), ldb, slabs.data_ptr(), ldc, M, N, K, S,
+                                           M * ldc, st()), "gemm_kk")
+            torch.cuda.synchronize()
+            out = slabs[:, :, :N].double().sum(0).cpu()
+            assert torch.isfinite(out).all(), (S, ldc)
+            err = (out - ref).abs().max().item()
+            assert err <= 2e-6 * scale, (S, ldc, err, scale)
+            if ldc > N:                            # nothing written between the rows
+                assert torch.isnan(slabs[:, :, N:]).all()
+
+
+def test_gemm_kk_rejects_unsupported_operands(lib):
+    """-2 for shapes / alignments the register-direct loads cannot take (the engine then keeps the tiled kernel)."""
+    A = dev(torch.zeros(64, 136))
+    Bm = dev(torch.zeros(64, 66))
+    C = torch.empty(132, 64, device="cuda")
+    ok = lambda *a: lib.sca_gemm_kk_supported(*a)
+    assert ok(A.data_ptr(), 136, Bm.data_ptr(), 66, 132, 64) == 1
+    assert ok(A.data_ptr(), 136, Bm.data_ptr(), 66, 130, 64) == 0          # M % 4 != 0
+    assert ok(A.data_ptr(), 134, Bm.data_ptr(), 66, 132, 64) == 0          # lda % 4 != 0
+    assert ok(A.data_ptr(), 136, Bm.data_ptr(), 65, 132, 64) == 0          # ldb % 2 != 0
+    assert ok(A.data_ptr(), 136, Bm.data_ptr(), 66, 132, 63) == 0          # N % 2 != 0
+    assert ok(A.data_ptr() + 4, 136, Bm.data_ptr(), 66, 132, 64) == 0      # A not 16-byte aligned
+    assert ok(A.data_ptr(), 136, Bm.data_ptr() + 4, 66, 132, 64) == 0      # B not 8-byte aligned
+    for args in ((A.data_ptr(), 136, Bm.data_ptr(), 66, C.data_ptr(), 64, 130, 64, 64, 1, 0),
+                 (A.data_ptr() + 4, 136, Bm.data_ptr(), 66, C.data_ptr(), 64, 132, 64, 64, 1, 0),
+                 (A.data_ptr(), 136, Bm.data_ptr() + 4, 66, C.data_ptr(), 64, 132, 64, 64, 1, 0)):
+        assert lib.sca_gemm_kk_f32(*args, st()) == -2
+    assert lib.sca_gemm_kk_f32(A.data_ptr(), 136, Bm.data_ptr(), 66, C.data_ptr(), 32, 132, 64, 64, 1, 0, st()) == -1
+
+
 @pytest.mark.parametrize("S,n", [(128, 81920), (33, 1000), (64, 4 * 17), (40, 10240)])
 def test_slab_reduce_many_slabs(lib, S, n):
     """sca_splitk_reduce with many slabs of a short vector (the MMD gradient slabs): the wide kernel (16 slab groups per

@@ -5,6 +5,7 @@
   * scPoli.classify (prototype=True and on cells, distance / probability forms, scaled uncertainties),
     get_recon_loss (own and substituted condition encoders) and add_new_cell_type against the real scPoli wrapper
     (models/scpoli/scpoli.py:213-315, scpoli_model.py:411-519,919-947), reparameterisation noise off on both sides;
+  * scPoli.shot_surgery (scpoli_model.py:842-917): substitution losses, mapping and copied parameters;
   * EXPIMAP.latent_enrich Bayes factors (models/expimap/expimap_model.py:445-591, exact=True) under the same numpy seed.
 """
 import contextlib
@@ -125,6 +126,59 @@ def test_scpoli_add_new_cell_type_matches_reference(scpoli_model):
     assert mean.shape == z["new_protos"].shape and cov.shape == z["new_protos_cov"].shape
     assert np.allclose(mean, z["new_protos"], rtol=1e-6, atol=1e-7)
     assert np.allclose(cov, z["new_protos_cov"], rtol=1e-4, atol=1e-5)
+
+
+def test_scpoli_shot_surgery_matches_reference():
+    """scPoli.shot_surgery (scpoli_model.py:842-917, train_epochs = 0) against the real wrapper: the reconstruction loss
+    of every (new study, reference study) substitution as printed, the chosen mapping, and the embedding rows / theta
+    columns copied into the returned model."""
+    import re
+    from scarches_amd.anndata_lite import CellData
+    from scarches_amd.engine import CVAEEngine
+    from scarches_amd.models import scPoli
+    z = np.load(os.path.join(GOLDEN, "scpoli_shot.npz"))
+    ad = CellData(z["X"], pd.DataFrame({"study": z["study"].astype(str), "cell_type": z["cell_type"].astype(str)}))
+    torch.manual_seed(11)
+    ref = quiet(scPoli, ad, condition_keys="study", cell_type_keys="cell_type", hidden_layer_sizes=[20], latent_dim=5,
+                embedding_dims=4, recon_loss="nb", dr_rate=0.0)
+    ref.model.load_state_dict({k[2:]: torch.tensor(z[k]) for k in z.files if k.startswith("w/")})
+    adq = CellData(z["Xq"], pd.DataFrame({"study": z["study_q"].astype(str),
+                                          "cell_type": z["cell_type_q"].astype(str)}))
+    buf = io.StringIO()
+    CVAEEngine.noise_off = True            # the wrapper builds the query model itself: switch the noise off class-wide
+    try:
+        torch.manual_seed(12)
+        with contextlib.redirect_stdout(buf):
+            model, mapping = scPoli.shot_surgery(adq, ref, labeled_indices=list(range(len(z["Xq"]))), train_epochs=0,
+                                                 batch_size=16)
+    finally:
+        CVAEEngine.noise_off = False
+    assert list(model.conditions_["study"]) == [str(s) for s in z["conditions"]]
+    want = dict(zip((str(s) for s in z["loss_keys"]), z["loss_vals"]))
+    got, cur = {}, None
+    for line in buf.getvalue().splitlines():
+        m1 = re.match(r"Processing (\S+)\.", line.strip())
+        m2 = re.match(r"Using (\S+), recon loss ([-0-9.e+]+)\.", line.strip())
+        if m1:
+            cur = m1.group(1)
+        elif m2:
+            got[f"{cur}|{m2.group(1)}"] = float(m2.group(2))
+    assert set(got) == set(want) and len(want) == 6
+    for k, v in want.items():
+        assert abs(got[k] - v) <= 1e-5 * abs(v), (k, got[k], v)
+    assert mapping == dict(zip((str(s) for s in z["map_new"]), (str(s) for s in z["map_old"])))
+    emb = model.model.embeddings[0].weight.detach().cpu().numpy()
+    theta = model.model.theta.detach().cpu().numpy()
+    # (the forward passes of get_recon_loss renormalise the touched embedding rows in place - nn.Embedding(max_norm),
+    #  scpoli.py:99-101 - which the HIP kernel does to the last bit or one ulp off: compare to 1e-6, copies exactly)
+    assert np.allclose(emb, z["emb_after"], rtol=1e-6, atol=1e-7) and np.allclose(theta, z["theta_after"], rtol=1e-6)
+    enc = model.model.condition_encoders["study"]
+    comb = model.model.conditions_combined_encoder
+    for new, old in mapping.items():
+        assert np.array_equal(emb[enc[new]], emb[enc[old]]) and np.array_equal(theta[:, comb[new]], theta[:, comb[old]])
+    # the query model maps its cells with the borrowed embeddings right away
+    lat = model.get_latent(adq, mean=True)
+    assert lat.shape == (len(z["Xq"]), 5) and np.isfinite(lat).all()
 
 
 def test_expimap_latent_enrich_matches_reference():
