@@ -44,10 +44,6 @@ def parse():
                     help="N > 1 only: MMD over each rank's slice (default: weak scaling keeps the O(B^2) MMD work per "
                          "GPU fixed) or the reference's MMD over the global minibatch (all-gather of z; O(B_global^2) "
                          "per rank - meant for the reference's batch sizes, not for 8 x 8192 cells)")
-    ap.add_argument("--launch-priority", choices=["high", "normal"], default="normal",
-                    help="priority of the stream the steps are issued on (the engine's side streams stay normal); "
-                         "'high' is faster (0.657 -> 0.641 ms per 8192-cell step) but hung in processes that had run "
-                         "other engines before (DESIGN.md, stream schedule): opt-in, single-GPU runs only")
     ap.add_argument("--launch", choices=["auto", "plan", "graph", "eager"], default="auto",
                     help="recorded launch plan, HIP-graph replay, eager launches, or auto (graph for B <= 4096, plan above)")
     return ap.parse_args()
@@ -268,15 +264,7 @@ def main():
     gen.manual_seed(2020 + rank)
 
     def run(Bx, steps, warmup):
-        # the steps are issued on the engine's high-priority launch stream (its side work runs at normal priority)
-        # (launch-plan batch sizes only: smaller steps replay HIP graphs on the caller's stream)
-        hp = (eng.launch_stream() if (a.launch_priority == "high" and Bx > 4096 and world == 1)
-              else torch.cuda.current_stream(dev))
-        hp.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(hp):
-            dt = run_on_stream(Bx, steps, warmup)
-        torch.cuda.current_stream(dev).wait_stream(hp)
-        return dt
+        return run_on_stream(Bx, steps, warmup)
 
     def run_on_stream(Bx, steps, warmup):
         # (one minibatch more than steps: the loader runs one minibatch ahead - every timed step gathers one, the

@@ -99,6 +99,8 @@ class CVAEEngine:
         self._adam_after_tail = None    # (weight_decay, wd_overrides): train_step on one device queues Adam on the aux stream
         self._dp_dry = False            # True while a warm-up / recording pass runs: data-parallel gathers stay local
         self._adam_done = False
+        self._dp_split = False          # True while a data-parallel step is issued: all-reduce between tail and Adam
+        self._dp_world, self._dp_grad_weight = 1, None
         self._mid_max_split = None      # optional split-K cap of the two GEMMs whose slabs the fused kernels sum
         self.lib = _RecordingLib(_lib.load(), self)
         self.device = torch.device(device)
@@ -336,7 +338,6 @@ class CVAEEngine:
         self.aux = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("SCA_AUX_PRIO", "0")))
         # output-layer weight gradient beside the dX chain
         self.aux2 = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("SCA_AUX2_PRIO", "0")))
-        self._launch_stream = None
         self._lanes_used = set()
         self._events = [torch.cuda.Event() for _ in range(128)]
         self._ev_i = 0
@@ -355,18 +356,6 @@ class CVAEEngine:
         self.use_fused_mid = (self.arch == "trvae" and not self.use_bn and self.recon in ("nb", "mse")
                               and len(self.enc) - 1 <= 4 and 1 <= len(self.dec) <= 4
                               and max(self.H) <= wmax and 3 * self.Zt <= wmax and bool(s.get("fused_mid", True)))
-
-    def launch_stream(self) -> "torch.cuda.Stream":
-        """A HIGH-priority stream for the caller to run its steps on (`with torch.cuda.stream(eng.launch_stream())`).
-        The step's critical chain is issued on the caller's current stream, its side work (MMD, weight gradients) on
-        the engine's normal-priority aux streams; on a high-priority launch stream the chain's workgroups are placed
-        ahead of the side kernels' whenever both wait for CU slots - the likelihood kernel then gets its 512 workgroups
-        resident at once instead of trickling in behind the MMD's 4096 (0.657 -> 0.641 ms per 8192-cell step).
-        OPT-IN (bench.py --launch-priority high, trainers with SCA_LAUNCH_PRIORITY=high): steps issued this way hung twice
-        in test processes that had driven other engines before; train_step never replays HIP graphs on such a stream."""
-        if self._launch_stream is None:
-            self._launch_stream = torch.cuda.Stream(device=self.device, priority=-1)
-        return self._launch_stream
 
     # ------------------------------------------------------------------------------------------ configuration
     def set_hyper(self, alpha_kl=None, lr=None, eps=None, clip=None, t=None, log_weight=None):
@@ -815,8 +804,23 @@ class CVAEEngine:
         self._defer(self._run_tail, lane=lane, join=join)
         fused = self._adam_after_tail
         if fused is not None:
+            if self._dp_split:
+                # data parallel: the ONE all-reduce of the flat gradient buffer is part of the step's recorded launch
+                # sequence, issued from the stream the tail runs on (RCCL orders itself behind the stream it is called
+                # from), so it starts the moment the last reduction is done and Adam follows it on the same stream
+                self._defer(lambda sa: self._call(self._dp_allreduce_on, lane), lane=lane)
             self._defer(lambda sa: self.adam_step(fused[0], fused[1], stream=sa), lane=lane)
             self._adam_done = True
+
+    def _dp_allreduce_on(self, lane):
+        """Gradient all-reduce of a data-parallel step (a host call recorded into the launch plan).  Warm-up and
+        recording passes skip it: a rank records a plan when ITS batch size is new, so the collective would be
+        unmatched on the other ranks (_dp_dry)."""
+        if self._dp_dry or self._dp_world <= 1:
+            return
+        from . import distributed as sdist
+        with torch.cuda.stream(self._lane_stream(lane)):
+            sdist.allreduce_mean_(self.flat_g, self._dp_world, weight=self._dp_grad_weight)
 
     def _run_tail(self, st):
         jobs, self._tail_jobs = self._tail_jobs, []
@@ -1840,13 +1844,14 @@ class CVAEEngine:
         tail and Adam - and the next call, given the same tensor (same storage, unmodified), starts at its first GEMM
         instead of the gather: the loader runs ahead of the model as the reference's DataLoader workers do.  Results
         are those of the un-pipelined sequence (same kernel, same inputs, same order of the arithmetic)."""
-        if use_graph is True and torch.cuda.current_stream(self.device).priority < 0:
-            use_graph = "plan"      # no HIP-graph replays on a high-priority stream (see launch_stream / trainers)
         if use_graph == "auto":
             # (world > 1: the gradient all-reduce is a host call between the two replayed halves of the step.  The
             # intermittent hangs of bench.py's two-rank one-GPU rehearsal came from ProcessGroupGloo's device-tensor
             # path, not from the launch mode: see distributed._host_staged.)
-            use_graph = True if (B <= 4096 and torch.cuda.current_stream(self.device).priority >= 0) else "plan"
+            use_graph = True if (B <= 4096 and world <= 1) else "plan"
+        self._dp_world, self._dp_grad_weight = int(world), grad_weight
+        if world > 1 and use_graph is True:
+            use_graph = "plan"      # the all-reduce is a host call inside the recorded sequence (not graph-captured)
         dp_exact = world > 1 and self._dp_exact()
         if dp_exact:
             self._dp_n_global = int(n_global) if n_global is not None else B * world
@@ -1860,8 +1865,6 @@ class CVAEEngine:
             self.begin_step(alpha_kl, lr, eps, clip)
             self._pf_flags = (False, False)
             self._step_and_adam(row_ids, cond, B, weight_decay, wd_overrides, world > 1)
-            if world > 1:
-                self._allreduce_and_adam(world, grad_weight, weight_decay, wd_overrides)
             return self.losses
         def plan_key():
             return (B, use_graph is True, float(weight_decay), tuple(sorted((wd_overrides or {}).items())), world > 1,
@@ -1923,8 +1926,6 @@ class CVAEEngine:
         # what ws["x"] holds once this step's launches have run: the next minibatch, or nothing to rely on
         self._pf = (dict(rows=next_rows, ptr=next_rows.data_ptr(), version=next_rows._version, B=B, gen=self._ws_gen,
                          csr=self.csr[0].data_ptr()) if do_next else None)
-        if world > 1:
-            self._allreduce_and_adam(world, grad_weight, weight_decay, wd_overrides)
         return self.losses
 
     def _pf_possible(self, next_rows, B):
@@ -1945,38 +1946,27 @@ class CVAEEngine:
                 and row_ids.data_ptr() == pf["ptr"] and row_ids.numel() == B and row_ids.is_contiguous()
                 and row_ids._version == pf["version"] and pf["rows"]._version == pf["version"])
 
-    def _allreduce_and_adam(self, world, grad_weight, weight_decay, wd_overrides):
-        """Data-parallel end of a step: ONE all-reduce of the flat gradient buffer and the replicated Adam update, both
-        queued on the aux stream - the stream the gradient tail just ran on - so the collective starts the moment the
-        last reduction is done (RCCL orders itself after the stream it is issued from) and Adam waits for nothing but
-        the collective; the main stream joins once, behind Adam."""
-        from . import distributed as sdist
-        main = torch.cuda.current_stream(self.device)
-        if not self.overlap:
-            sdist.allreduce_mean_(self.flat_g, world, weight=grad_weight)
-            self.adam_step(weight_decay, wd_overrides)
-            return
-        ev = self._next_event()
-        ev.record(main)
-        self.aux.wait_event(ev)
-        with torch.cuda.stream(self.aux):
-            sdist.allreduce_mean_(self.flat_g, world, weight=grad_weight)
-            self.adam_step(weight_decay, wd_overrides, stream=self.aux.cuda_stream)
-        ev2 = self._next_event()
-        ev2.record(self.aux)
-        main.wait_event(ev2)
-
     def _step_and_adam(self, rows, cond, B, weight_decay, wd_overrides, split):
-        """forward + backward and - unless a gradient all-reduce sits between them (`split`) - Adam, queued right
-        behind the gradient tail on the aux stream."""
-        self._adam_after_tail = None if split else (weight_decay, wd_overrides)
+        """forward + backward, the gradient all-reduce of a data-parallel step (`split`) and Adam, the last two queued
+        right behind the gradient tail on its aux stream."""
+        self._adam_after_tail = (weight_decay, wd_overrides)
+        self._dp_split = bool(split)
         self._adam_done = False
         try:
             self.forward_backward(rows, cond, B)
+            if not self._adam_done:                 # paths without a deferred tail (overlap off)
+                if split:
+                    self._call(self._dp_allreduce_main)
+                self.adam_step(weight_decay, wd_overrides)
         finally:
             self._adam_after_tail = None
-        if not split and not self._adam_done:       # paths without a deferred tail (overlap off)
-            self.adam_step(weight_decay, wd_overrides)
+            self._dp_split = False
+
+    def _dp_allreduce_main(self):
+        if self._dp_dry or self._dp_world <= 1:
+            return
+        from . import distributed as sdist
+        sdist.allreduce_mean_(self.flat_g, self._dp_world, weight=self._dp_grad_weight)
 
     @staticmethod
     def _replay(plan):
@@ -2015,7 +2005,7 @@ class CVAEEngine:
         self._dp_dry = True            # the launches run while they are recorded; the replays gather for real
         try:
             self._step_and_adam(rows, cond, B, weight_decay, wd_overrides, split)
-            out["fwd"] = self._rec     # (split: Adam follows the gradient all-reduce, _allreduce_and_adam)
+            out["fwd"] = self._rec     # (split: the gradient all-reduce sits between the tail and Adam, _defer_tail)
         finally:
             self._rec = None
             self._dp_dry = False

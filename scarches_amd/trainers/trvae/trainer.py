@@ -177,31 +177,20 @@ class Trainer:
         self._eps = eps
         tr = self._train_dev
         self.before_loop()
-        # Opt-in (SCA_LAUNCH_PRIORITY=high, single GPU, launch-plan batch sizes): the steps are issued on the engine's
-        # high-priority launch stream - the critical chain's workgroups are then placed ahead of the side kernels' (MMD,
-        # weight gradients), which run on normal-priority aux streams: 0.657 -> 0.641 ms per 8192-cell step.  Not the
-        # default: a step issued that way hung twice in test processes that had driven other engines before (a HIP-graph
-        # replay at batch 128, a launch plan at 8192 after three default-stream engines); cause not found.
-        cur = torch.cuda.current_stream(self.device)
-        hp = (self.engine.launch_stream()
-              if self.batch_size > 4096 and self.world == 1 and os.environ.get("SCA_LAUNCH_PRIORITY") == "high" else cur)
-        hp.wait_stream(cur)
-        with torch.cuda.stream(hp):
-            for self.epoch in range(n_epochs):
-                self.on_epoch_begin(lr, eps)
-                self.engine.bind_csr(tr["indptr"], tr["indices"], tr["data"])
-                self.engine.accum.zero_()
-                # one minibatch of look-ahead: the engine gathers minibatch i + 1 beside the tail of step i
-                batches = iter(self._epoch_batches())
-                batch_data, i = next(batches, None), 0
-                while batch_data is not None:
-                    self.iter, self._next_batch = i, next(batches, None)
-                    self.on_iteration(batch_data)
-                    batch_data, i = self._next_batch, i + 1
-                self.on_epoch_end()
-                if self.use_early_stopping and not self.check_early_stop():
-                    break
-        cur.wait_stream(hp)
+        for self.epoch in range(n_epochs):
+            self.on_epoch_begin(lr, eps)
+            self.engine.bind_csr(tr["indptr"], tr["indices"], tr["data"])
+            self.engine.accum.zero_()
+            # one minibatch of look-ahead: the engine gathers minibatch i + 1 beside the tail of step i
+            batches = iter(self._epoch_batches())
+            batch_data, i = next(batches, None), 0
+            while batch_data is not None:
+                self.iter, self._next_batch = i, next(batches, None)
+                self.on_iteration(batch_data)
+                batch_data, i = self._next_batch, i + 1
+            self.on_epoch_end()
+            if self.use_early_stopping and not self.check_early_stop():
+                break
         if self.best_state_dict is not None and self.reload_best:
             print("Saving best state of network...")
             print("Best State was in Epoch", self.best_epoch)
