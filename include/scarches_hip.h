@@ -125,6 +125,24 @@ int sca_recon_rows(int zinb, float* logits, int ldl, float* pi, const int64_t* i
                    const float* tab_theta, const float* tab_lte, int B, int G, int C, int rows_per_block, float* row_ll,
                    float* dthetaT, float* dbias, float* dbias_pi, int compute_grad, const float* cond_off,
                    float* row_dsf, void* stream);
+
+/* ---- output layer fused with the NB likelihood (round 3) -------------------------------------------------------
+ * sca_out_nb_fused = sca_gemm_f32 (logits = h W^T + bias; models/trvae/modules.py:179-181,207) + sca_recon_rows
+ * (zinb = 0: softmax, mu = gamma * sizefactor, theta = exp(theta[:, c]), NB log-likelihood and its backward;
+ * trvae.py:136-141, losses.py:63-102) in ONE launch: the logits stay in MFMA accumulator registers, only d loss /
+ * d logits is written (dl [B][ldl]; it also serves as scratch for the raw logits while the kernel runs).  Outputs as
+ * sca_recon_rows: row_ll [B], dthetaT [C][G] (accumulated, pre-zeroed), dbias [G] (accumulated, pre-zeroed, may be
+ * NULL).  gam_tab [C][G][17][2]: (lgamma, digamma) differences of integer counts 0..16 per (condition, gene), built by
+ * sca_nb_gamma_table from tab_theta once per step; ext_ovf [B][ld_ovf >= G]: scratch touched only by cells with more
+ * than 512 stored counts.  h / W: 16-byte aligned, ldh / ldw multiples of 4.  Shapes: sca_out_nb_fused_supported(G, K)
+ * (G <= 2048, K a multiple of 16 up to 256; SCA_OUT_FUSED=0 switches it off for A/B runs), else -2. */
+int sca_out_nb_fused_supported(int G, int K);
+int sca_nb_gamma_table(const float* tab_theta, int C, int G, float* gam_tab, void* stream);
+int sca_out_nb_fused(const float* h, int ldh, const float* W, int ldw, const float* bias, const int64_t* indptr,
+                     const int32_t* indices, const float* data, const int64_t* row_ids, const float* sizefactor,
+                     const int32_t* cond, const float* tab_theta, const float* gam_tab, int B, int G, int K, int C,
+                     float* dl, int ldl, float* ext_ovf, int ld_ovf, float* row_ll, float* dthetaT, float* dbias,
+                     int compute_grad, void* stream);
 /* sca_poisson_rows: scPoli's 'poisson' head (models/scpoli/scpoli.py:189-191,607,640; models/trvae/losses.py:44-60): the
  * softmax output is the Poisson rate, row_loss[b] = sum_g [rate - xlogy(x, rate) + lgamma(x + 1)] with counts from CSR,
  * d (sum_b row_loss / B) / d logits written in place; sizefactor[b] = sum_g x_bg. */
