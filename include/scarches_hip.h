@@ -135,9 +135,13 @@ int sca_recon_rows(int zinb, float* logits, int ldl, float* pi, const int64_t* i
  * NULL).  gam_tab [C][G][17][2]: (lgamma, digamma) differences of integer counts 0..16 per (condition, gene), built by
  * sca_nb_gamma_table from tab_theta once per step; ext_ovf [B][ld_ovf >= G]: scratch touched only by cells with more
  * than 512 stored counts.  h / W: 16-byte aligned, ldh / ldw multiples of 4.  Shapes: sca_out_nb_fused_supported(G, K)
- * (G <= 2048, K a multiple of 16 up to 256; SCA_OUT_FUSED=0 switches it off for A/B runs), else -2. */
+ * (G <= 2048, K in {32, 64, 128, 256}), else -2.
+ * Measured on MI355X: not yet faster than the pair it replaces - the engine uses it only with
+ * SCA_OUT_FUSED=1. */
 int sca_out_nb_fused_supported(int G, int K);
 int sca_nb_gamma_table(const float* tab_theta, int C, int G, float* gam_tab, void* stream);
+/* development aid: 12 s_memrealtime marks per workgroup of the next sca_out_nb_fused launches (NULL: off, the default) */
+int sca_out_nb_fused_debug_stamps(long long* buf);
 int sca_out_nb_fused(const float* h, int ldh, const float* W, int ldw, const float* bias, const int64_t* indptr,
                      const int32_t* indices, const float* data, const int64_t* row_ids, const float* sizefactor,
                      const int32_t* cond, const float* tab_theta, const float* gam_tab, int B, int G, int K, int C,

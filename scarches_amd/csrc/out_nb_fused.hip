@@ -34,12 +34,12 @@ namespace {
 
 constexpr float ON_EPS = 1e-8f;
 constexpr int ON_ROWS = 16;          // cells per workgroup
-constexpr int ON_NW = 8;             // waves per workgroup
+constexpr int ON_NW = 16;            // waves per workgroup (one workgroup per CU: four waves per SIMD)
 constexpr int ON_T = ON_NW * 64;
-constexpr int ON_TPW = 16;           // tiles of 16 genes per wave (register budget): G <= 16 * 16 * 8 = 2048
+constexpr int ON_TPW = 8;            // tiles of 16 genes per wave (32 accumulator registers): G <= 8 * 16 * 16 = 2048
 constexpr int ON_GMAX = ON_TPW * 16 * ON_NW;
 constexpr int ON_RS = 512;           // LDS slots per cell for the stored counts' extras
-constexpr int ON_QW = 128;           // heavy-path queue entries per wave
+constexpr int ON_QW = 128;           // heavy-path compaction queue per wave (two chunks)
 constexpr int ON_NX = 17;            // tabulated counts 0 .. 16
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.69314718055994530942f;
 
@@ -60,6 +60,8 @@ struct OutNbArgs {
     float* dthetaT;                      // [C][G] accumulates sum_b theta dll/dtheta (pre-zeroed)
     float* dbias;                        // [G] accumulates column sums of d logits (pre-zeroed; may be null)
     int compute_grad;
+    long long* stamps;                   // debug: [workgroup][12] s_memrealtime marks of thread 0 (NULL in production)
+    int abl;                             // debug ablation mask (SCA_OUT_ABL): timing probes only, results are wrong
 };
 
 // (lgam, dig) of integer counts 1..16 per (condition, gene): the loop of recon_loss.hip's fast path, run once per
@@ -91,10 +93,11 @@ __device__ __forceinline__ float ld_l2(const float* p) {      // L1-bypassing lo
 __device__ __forceinline__ float xor16(float v) { return __shfl_xor(v, 16, 64); }
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 
+template <int CPP>      // K / 32: chunks of two 16-deep k-steps per tile pair
 __global__ __launch_bounds__(ON_T, 4) void out_nb_fused_kernel(const OutNbArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int G = a.G, K = a.K;
-    const int PITCH = K + 8;
+    const int G = a.G;
+    constexpr int K = 32 * CPP, PITCH = K + 8;
     const int Gp = (G + 3) & ~3;
     float* hA = lds;                                  // [16][PITCH]
     float* dxs = hA + ON_ROWS * PITCH;                // [Gp] theta gradient of the workgroup (one condition)
@@ -109,6 +112,8 @@ __global__ __launch_bounds__(ON_T, 4) void out_nb_fused_kernel(const OutNbArgs a
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, n = lane & 15, kg = lane >> 4;
     const int r0 = blockIdx.x * ON_ROWS, nrows = min(ON_ROWS, a.B - r0);
     const float invB = 1.0f / (float)a.B;
+#define ON_STAMP(i) do { if (a.stamps && t == 0) a.stamps[(long long)blockIdx.x * 12 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+    ON_STAMP(0);
 
     // ---- 0. row scalars, activation tile, cleared accumulators
     if (t < ON_ROWS) {
@@ -136,6 +141,7 @@ __global__ __launch_bounds__(ON_T, 4) void out_nb_fused_kernel(const OutNbArgs a
         }
     }
     __syncthreads();
+    ON_STAMP(1);
     const int c0 = s_c[0];
     bool uni = true;
 #pragma unroll
@@ -146,40 +152,64 @@ __global__ __launch_bounds__(ON_T, 4) void out_nb_fused_kernel(const OutNbArgs a
     const int T0 = w * tpw, ntw = max(0, min(tpw, NT - T0));
     f32x4 acc[ON_TPW];
     {
+        // A chunk = two 16-deep k-steps (2 x 8 MFMAs) of a PAIR of tiles = four 16-byte W loads per lane.  The loads of
+        // chunk i + 1 are issued before chunk i feeds the MFMAs (unconditional, fixed in number: counted vmcnt waits; a
+        // chunk is 512 cycles of matrix work and four waves share the SIMD's pipe, so ~2000 cycles pass before the next
+        // chunk is needed); tiles past the wave's last one read clamped rows, their accumulators are discarded below.
         const float* arow = hA + n * PITCH + 4 * kg;
-        const int ks4 = K >> 4;
+        constexpr int NCH = (ON_TPW / 2) * CPP;
+        unsigned woff[ON_TPW];           // byte offsets of this lane's W rows
 #pragma unroll
-        for (int tp = 0; tp < ON_TPW / 2; ++tp) {
-            if (2 * tp < ntw) {
-                const int g0 = 16 * (T0 + 2 * tp) + n, g1 = g0 + 16;
-                const bool v1 = 2 * tp + 1 < ntw;
-                const float b0 = g0 < G ? a.bias[g0] : -INFINITY;
-                const float b1 = (v1 && g1 < G) ? a.bias[g1] : -INFINITY;
-                f32x4 x0 = {b0, b0, b0, b0}, x1 = {b1, b1, b1, b1};
-                const float* w0 = a.W + (long long)min(g0, G - 1) * a.ldw + 4 * kg;
-                const float* w1 = a.W + (long long)min(g1, G - 1) * a.ldw + 4 * kg;
-                for (int s = 0; s < ks4; ++s) {
-                    const float4 av = *reinterpret_cast<const float4*>(arow + 16 * s);
-                    const float4 p0 = *reinterpret_cast<const float4*>(w0 + 16 * s);
-                    const float4 p1 = *reinterpret_cast<const float4*>(w1 + 16 * s);
-                    x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, p0.x, x0, 0, 0, 0);
-                    x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, p1.x, x1, 0, 0, 0);
-                    x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, p0.y, x0, 0, 0, 0);
-                    x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, p1.y, x1, 0, 0, 0);
-                    x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, p0.z, x0, 0, 0, 0);
-                    x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, p1.z, x1, 0, 0, 0);
-                    x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, p0.w, x0, 0, 0, 0);
-                    x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, p1.w, x1, 0, 0, 0);
-                }
-                acc[2 * tp] = x0;
-                acc[2 * tp + 1] = x1;
-            } else {
-                acc[2 * tp] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                acc[2 * tp + 1] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int tl = 0; tl < ON_TPW; ++tl) {
+            const int gg = 16 * (T0 + tl) + n;
+            woff[tl] = ((unsigned)min(gg, G - 1) * (unsigned)a.ldw + 4u * kg) * 4u;
+            const float b = a.bias[min(gg, G - 1)];
+            acc[tl] = f32x4{b, b, b, b};
+        }
+        float4 ring[2][4];
+        auto issue = [&](int ci, float4 (&slot)[4]) {
+            const int tp = ci / CPP, q = ci % CPP;
+            const float* w0 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.W) + (woff[2 * tp] + 128u * q));
+            const float* w1 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.W) + (woff[2 * tp + 1] + 128u * q));
+            slot[0] = *reinterpret_cast<const float4*>(w0);
+            slot[1] = *reinterpret_cast<const float4*>(w0 + 16);
+            slot[2] = *reinterpret_cast<const float4*>(w1);
+            slot[3] = *reinterpret_cast<const float4*>(w1 + 16);
+        };
+        auto mma8 = [&](f32x4& x0, f32x4& x1, const float4& av, const float4& p0, const float4& p1) {
+            x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, p0.x, x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, p1.x, x1, 0, 0, 0);
+            x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, p0.y, x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, p1.y, x1, 0, 0, 0);
+            x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, p0.z, x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, p1.z, x1, 0, 0, 0);
+            x0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, p0.w, x0, 0, 0, 0);
+            x1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, p1.w, x1, 0, 0, 0);
+        };
+        if (!(a.abl & 1)) {
+            issue(0, ring[0]);
+#pragma unroll
+            for (int ci = 0; ci < NCH; ++ci) {
+                if (ci + 1 < NCH) issue(ci + 1, ring[(ci + 1) % 2]);
+                const int tp = ci / CPP, q = ci % CPP;
+                const float4 av0 = *reinterpret_cast<const float4*>(arow + 32 * q);
+                const float4 av1 = *reinterpret_cast<const float4*>(arow + 32 * q + 16);
+                mma8(acc[2 * tp], acc[2 * tp + 1], av0, ring[ci % 2][0], ring[ci % 2][2]);
+                mma8(acc[2 * tp], acc[2 * tp + 1], av1, ring[ci % 2][1], ring[ci % 2][3]);
             }
         }
+#pragma unroll
+        for (int tl = 0; tl < ON_TPW; ++tl)
+            if (!(tl < ntw && 16 * (T0 + tl) + n < G)) acc[tl] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     }
+    ON_STAMP(2);
     // ---- 2. raw logits -> d-logits buffer (the stored counts read theirs back), wave-local softmax statistics
+    // (32-bit byte offsets from the uniform base pointer: one address register per store instead of a 64-bit pair
+    //  per (cell, tile) that the compiler would keep alive until the second pass; B * ldl < 2^30, checked by the host)
+    unsigned rowb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rowb[r] = (unsigned)(r0 + min(4 * kg + r, nrows - 1)) * (unsigned)a.ldl * 4u;
+    auto DL = [&](unsigned byteoff) -> float& { return *reinterpret_cast<float*>(reinterpret_cast<char*>(a.dl) + byteoff); };
     float mw[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
     for (int tl = 0; tl < ON_TPW; ++tl) {
@@ -188,7 +218,7 @@ __global__ __launch_bounds__(ON_T, 4) void out_nb_fused_kernel(const OutNbArgs a
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * kg + r;
-                if (row < nrows && g < G) a.dl[(long long)(r0 + row) * a.ldl + g] = acc[tl][r];
+                if (row < nrows && g < G && !(a.abl & 32)) DL(rowb[r] + 4u * (unsigned)g) = acc[tl][r];
                 mw[r] = fmaxf(mw[r], acc[tl][r]);
             }
         }
@@ -211,8 +241,10 @@ __global__ __launch_bounds__(ON_T, 4) void out_nb_fused_kernel(const OutNbArgs a
         sw[r] = row16_sum(sw[r]);
         if (n == 0) { s_m[w][4 * kg + r] = mw[r]; s_s[w][4 * kg + r] = sw[r]; }
     }
+    ON_STAMP(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's logits have reached L2
     __syncthreads();
+    ON_STAMP(4);
 
     // row statistics M = max_w m_w, S = sum_w s_w exp(m_w - M)  (every lane, for any row it needs)
     auto row_stats = [&](int row, float& M, float& iS) {
@@ -237,9 +269,10 @@ __global__ __launch_bounds__(ON_T, 4) void out_nb_fused_kernel(const OutNbArgs a
         fmu[r] = fgam[r] * s_sf[4 * kg + r];
     }
 
-    // ---- 3. stored counts: wave w takes cells 2 w and 2 w + 1, one lane per count
-    for (int rr = 2 * w; rr < 2 * w + 2; ++rr) {
-        if (rr >= nrows) break;
+    ON_STAMP(5);
+    // ---- 3. stored counts: wave w takes cell w, one lane per count
+    if (w < nrows && !(a.abl & 2)) {
+        const int rr = w;
         const long long ks = s_ks[rr];
         const int nn = s_nn[rr], c = s_c[rr];
         const float s = s_sf[rr];
@@ -249,70 +282,69 @@ __global__ __launch_bounds__(ON_T, 4) void out_nb_fused_kernel(const OutNbArgs a
         const float2* gt = a.gam_tab + (long long)c * G * ON_NX;
         float* lrow = a.dl + (long long)(r0 + rr) * a.ldl;
         float all = 0.f, aT = 0.f;
-        float xn = 0.f; int gn = 0;
-        if (lane < nn) { xn = a.data[ks + lane]; gn = a.indices[ks + lane]; }
-        for (int base = 0; base < nn; base += 64) {
-            const int j = base + lane;
-            const float x = xn; const int g = gn;
-            if (j + 64 < nn) { xn = a.data[ks + j + 64]; gn = a.indices[ks + j + 64]; }      // next chunk in flight
-            float ex_t = 0.f;
-            if (j < nn && x > ON_EPS) {
-                const float lv = ld_l2(lrow + g);
-                const float th = tth[g];
-                float lgam = 0.f, dig = 0.f;
-                bool fast = false;
-                if (x <= 16.0f && x == floorf(x)) {
-                    const float2 tv = gt[(long long)g * ON_NX + (int)x];
-                    fast = tv.x == tv.x;
-                    lgam = tv.x; dig = tv.y;
+        // three-stage software pipeline over chunks of 64 counts: (A) count + gene index of chunk i + 2, (B) the loads
+        // that depend on them - logit, theta, table entry - of chunk i + 1, (C) the arithmetic of chunk i.  Every load
+        // is unconditional from a clamped address, so a chunk's dependent latencies overlap the previous chunks' work.
+        struct StA { float x; int g; };
+        struct StB { float x, lv, th; int g; float2 tv; bool isint; };
+        auto loadA = [&](int base) {
+            StA r;
+            const int jj = min(base + lane, nn - 1);
+            r.x = a.data[ks + jj];
+            r.g = a.indices[ks + jj];
+            return r;
+        };
+        auto loadB = [&](const StA& p) {
+            StB r;
+            r.x = p.x; r.g = p.g;
+            r.isint = p.x <= 16.0f && p.x == floorf(p.x);
+            r.lv = ld_l2(lrow + p.g);
+            r.th = tth[p.g];
+            r.tv = gt[(long long)p.g * ON_NX + (r.isint ? (int)p.x : 0)];
+            return r;
+        };
+        if (nn > 0) {
+            StA a1 = loadA(0);
+            StA a2 = loadA(64);
+            StB b0 = loadB(a1);
+            for (int base = 0; base < nn; base += 64) {
+                const StA a3 = loadA(base + 128);
+                const StB b1 = loadB(a2);
+                a2 = a3;
+                const int j = base + lane;
+                float ex_t = 0.f;
+                if (j < nn && b0.x > ON_EPS) {
+                    // (large / non-integer counts, theta outside the table: their gamma terms are added by the fp64
+                    //  sweep at the end of the kernel - neither T nor d-logits depends on them)
+                    const bool fast = b0.isint && b0.tv.x == b0.tv.x;
+                    const float lgam = fast ? b0.tv.x : 0.f, dig = fast ? b0.tv.y : 0.f;
+                    const float mu = __builtin_amdgcn_exp2f((b0.lv - M) * LOG2E) * iS * s;
+                    const float den = b0.th + mu + ON_EPS;
+                    const float L = fast_logf(den), rcp = __builtin_amdgcn_rcpf(den);
+                    all += b0.x * (fast_logf(mu + ON_EPS) - L) + lgam;
+                    ex_t = mu * b0.x * (__builtin_amdgcn_rcpf(mu + ON_EPS) - rcp);
+                    aT += ex_t;
+                    if (a.compute_grad) {
+                        const float ex_th = b0.th * (-b0.x * rcp + dig);
+                        if (uni) atomicAdd(&dxs[b0.g], ex_th);
+                        else atomicAdd(&a.dthetaT[(long long)c * G + b0.g], ex_th);
+                        atomicAdd(&dbs[b0.g], ex_t);
+                    }
                 }
-                if (!fast) {
-                    lgam = 0.f; dig = 0.f;
-                    const int slot = atomicAdd(&s_hqn[w], 1);
-                    if (slot < ON_QW) hq[w * ON_QW + slot] = j;
-                    else nb_gamma_terms_heavy(x, th, &lgam, &dig);
+                if (a.compute_grad && j < nn) {
+                    if (j < ON_RS) ext[rr * ON_RS + j] = ex_t;
+                    else a.ext_ovf[(long long)(r0 + rr) * a.ld_ovf + j] = ex_t;
                 }
-                const float mu = __builtin_amdgcn_exp2f((lv - M) * LOG2E) * iS * s;
-                const float den = th + mu + ON_EPS;
-                const float L = fast_logf(den), rcp = __builtin_amdgcn_rcpf(den);
-                all += x * (fast_logf(mu + ON_EPS) - L) + lgam;
-                ex_t = mu * x * (__builtin_amdgcn_rcpf(mu + ON_EPS) - rcp);
-                aT += ex_t;
-                if (a.compute_grad) {
-                    const float ex_th = th * (-x * rcp + dig);
-                    if (uni) atomicAdd(&dxs[g], ex_th);
-                    else atomicAdd(&a.dthetaT[(long long)c * G + g], ex_th);
-                    atomicAdd(&dbs[g], ex_t);
-                }
-            }
-            if (a.compute_grad && j < nn) {
-                if (j < ON_RS) ext[rr * ON_RS + j] = ex_t;
-                else a.ext_ovf[(long long)(r0 + rr) * a.ld_ovf + j] = ex_t;
+                b0 = b1;
             }
         }
-        // large / non-integer counts, compacted so that the fp64 code runs on full lanes
-        __builtin_amdgcn_wave_barrier();
-        const int nq = min(s_hqn[w], ON_QW);
-        for (int q = lane; q < nq; q += 64) {
-            const int j = hq[w * ON_QW + q];
-            const float x = a.data[ks + j];
-            const int g = a.indices[ks + j];
-            const float th = tth[g];
-            float lgam, dig;
-            nb_gamma_terms_heavy(x, th, &lgam, &dig);
-            all += lgam;
-            if (a.compute_grad) {
-                if (uni) atomicAdd(&dxs[g], th * dig);
-                else atomicAdd(&a.dthetaT[(long long)c * G + g], th * dig);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) s_hqn[w] = 0;
         all = wave_sum(all);
         aT = wave_sum(aT);
         if (lane == 0) { s_xll[rr] = all; s_xT[rr] = aT; }
     }
+    ON_STAMP(6);
     __syncthreads();
+    ON_STAMP(7);
 
     // ---- 4. dense sweep (the x = 0 terms of every gene), first pass: row sums and the theta gradient
     float llr[4] = {0.f, 0.f, 0.f, 0.f}, Tr[4] = {0.f, 0.f, 0.f, 0.f};
@@ -321,7 +353,7 @@ __global__ __launch_bounds__(ON_T, 4) void out_nb_fused_kernel(const OutNbArgs a
     for (int r = 0; r < 4; ++r) cr[r] = s_c[4 * kg + r];
 #pragma unroll
     for (int tl = 0; tl < ON_TPW; ++tl) {
-        if (tl < ntw) {
+        if (tl < ntw && !(a.abl & 4)) {
             const int g = 16 * (T0 + tl) + n, gi = min(g, G - 1);
             if (uni) {
                 const float th = a.tab_theta[(long long)c0 * G + gi];
@@ -372,13 +404,7 @@ __global__ __launch_bounds__(ON_T, 4) void out_nb_fused_kernel(const OutNbArgs a
         if (n == 0) { s_ll[w][4 * kg + r] = llr[r]; s_T[w][4 * kg + r] = Tr[r]; }
     }
     __syncthreads();
-    if (t < nrows) {
-        float ll = s_xll[t];
-#pragma unroll
-        for (int i = 0; i < ON_NW; ++i) ll += s_ll[i][t];
-        a.row_ll[r0 + t] = ll;
-    }
-    if (!a.compute_grad) return;
+    ON_STAMP(8);
     float Tt[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -391,7 +417,7 @@ __global__ __launch_bounds__(ON_T, 4) void out_nb_fused_kernel(const OutNbArgs a
     // ---- 5. second pass: d loss / d logits = (gamma T - t) / B from the registers
 #pragma unroll
     for (int tl = 0; tl < ON_TPW; ++tl) {
-        if (tl < ntw) {
+        if (tl < ntw && a.compute_grad && !(a.abl & 8)) {
             const int g = 16 * (T0 + tl) + n, gi = min(g, G - 1);
             float thu = 0.f;
             if (uni) thu = a.tab_theta[(long long)c0 * G + gi];
@@ -406,7 +432,7 @@ __global__ __launch_bounds__(ON_T, 4) void out_nb_fused_kernel(const OutNbArgs a
                 const float dlv = fmaf(e * fgam[r], Tt[r], -tv);
                 const int row = 4 * kg + r;
                 if (row < nrows && g < G) {
-                    a.dl[(long long)(r0 + row) * a.ldl + g] = dlv;
+                    DL(rowb[r] + 4u * (unsigned)g) = dlv;
                     bsum += dlv;
                 }
             }
@@ -415,12 +441,14 @@ __global__ __launch_bounds__(ON_T, 4) void out_nb_fused_kernel(const OutNbArgs a
             if (kg == 0 && g < G) dbs[g] = bsum - invB * dbs[g];
         }
     }
+    ON_STAMP(9);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    ON_STAMP(10);
 
     // ---- 6. stored positions: subtract their extra term (same wave, same lane as in phase 3); gradient flush
-    for (int rr = 2 * w; rr < 2 * w + 2; ++rr) {
-        if (rr >= nrows) break;
+    if (w < nrows && a.compute_grad && !(a.abl & 16)) {
+        const int rr = w;
         const long long ks = s_ks[rr];
         const int nn = s_nn[rr];
         float* lrow = a.dl + (long long)(r0 + rr) * a.ldl;
@@ -432,17 +460,88 @@ __global__ __launch_bounds__(ON_T, 4) void out_nb_fused_kernel(const OutNbArgs a
             }
         }
     }
+    // ---- 7. gamma terms of the counts the table does not hold (large / non-integer counts, theta out of range): the
+    //         cell's counts are scanned once more, the hits compacted through a per-wave queue so that the fp64 code
+    //         runs on full lanes.  Here - not in phase 3 - because the accumulator registers are dead by now.
+    float heavy_ll = 0.f;
+    if (w < nrows && !(a.abl & 2)) {
+        const int rr = w;
+        const long long ks = s_ks[rr];
+        const int nn = s_nn[rr], c = s_c[rr];
+        const float* tth = a.tab_theta + (long long)c * G;
+        const float2* gt = a.gam_tab + (long long)c * G * ON_NX;
+        int* q = hq + w * ON_QW;
+        int nq = 0;                                      // wave-uniform
+        auto drain = [&](int cnt) {                      // fp64 terms of q[0 .. cnt)
+            if (lane < cnt) {
+                const int j = q[lane];
+                const float x = a.data[ks + j];
+                const int g = a.indices[ks + j];
+                const float th = tth[g];
+                float lgam, dig;
+                nb_gamma_terms_heavy(x, th, &lgam, &dig);
+                heavy_ll += lgam;
+                if (a.compute_grad) {
+                    if (uni) atomicAdd(&dxs[g], th * dig);
+                    else atomicAdd(&a.dthetaT[(long long)c * G + g], th * dig);
+                }
+            }
+        };
+        for (int base = 0; base < nn; base += 64) {
+            const int j = base + lane;
+            bool need = false;
+            if (j < nn) {
+                const float x = a.data[ks + j];
+                if (x > ON_EPS) {
+                    const bool isint = x <= 16.0f && x == floorf(x);
+                    if (isint) {
+                        const float lg = gt[(long long)a.indices[ks + j] * ON_NX + (int)x].x;
+                        need = !(lg == lg);
+                    } else {
+                        need = true;
+                    }
+                }
+            }
+            const unsigned long long bal = __ballot(need);
+            if (bal) {
+                if (need) q[nq + __builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0))] = j;
+                nq += __popcll(bal);
+                __builtin_amdgcn_wave_barrier();
+                if (nq >= 64) {
+                    drain(64);
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < nq - 64) q[lane] = q[64 + lane];
+                    nq -= 64;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        drain(nq);
+        heavy_ll = wave_sum(heavy_ll);
+    }
+    if (w < nrows && lane == 0) {
+        float ll = s_xll[w] + heavy_ll;
+#pragma unroll
+        for (int i = 0; i < ON_NW; ++i) ll += s_ll[i][w];
+        a.row_ll[r0 + w] = ll;
+    }
+    if (!a.compute_grad) return;
+    __syncthreads();
     for (int g = t; g < G; g += ON_T) {
         if (uni) atomicAdd(&a.dthetaT[(long long)c0 * G + g], dxs[g]);
         if (a.dbias) atomicAdd(&a.dbias[g], dbs[g]);
     }
+    ON_STAMP(11);
 }
 
 }  // namespace
 
+static long long* g_on_stamps = nullptr;
+// development aid: 12 s_memrealtime marks per workgroup of the next launches (NULL: off, the default)
+extern "C" int sca_out_nb_fused_debug_stamps(long long* buf) { g_on_stamps = buf; return 0; }
+
 extern "C" int sca_out_nb_fused_supported(int G, int K) {
-    static const bool on = [] { const char* v = getenv("SCA_OUT_FUSED"); return !v || atoi(v) != 0; }();
-    return (on && G >= 1 && G <= ON_GMAX && K >= 16 && K <= 256 && (K & 15) == 0) ? 1 : 0;
+    return (G >= 1 && G <= ON_GMAX && (K == 32 || K == 64 || K == 128 || K == 256)) ? 1 : 0;
 }
 
 // gam_tab [C][G][17][2] floats from tab_theta [C][G] (sca_theta_prep): once per step, before sca_out_nb_fused.
@@ -467,17 +566,28 @@ extern "C" int sca_out_nb_fused(const float* h, int ldh, const float* W, int ldw
         return -1;
     if ((ldh & 3) || (ldw & 3) || ((uintptr_t)h & 15) || ((uintptr_t)W & 15)) return -2;
     if (compute_grad && (!dthetaT || !ext_ovf || ld_ovf < G)) return -1;
+    if ((long long)B * ldl >= (1ll << 30) || (long long)G * ldw >= (1ll << 30)) return -2;      // 32-bit byte offsets
     OutNbArgs a{h, ldh, W, ldw, bias, indptr, indices, data, row_ids, sizefactor, cond, tab_theta,
                 reinterpret_cast<const float2*>(gam_tab), B, G, K, C, dl, ldl, ext_ovf, ld_ovf, row_ll, dthetaT, dbias,
-                compute_grad};
+                compute_grad, g_on_stamps, [] { const char* v = getenv("SCA_OUT_ABL"); return v ? atoi(v) : 0; }()};
     const int Gp = (G + 3) & ~3;
     const size_t shm = sizeof(float) * ((size_t)ON_ROWS * (K + 8) + 2 * (size_t)Gp + (size_t)ON_ROWS * ON_RS +
                                         (size_t)ON_NW * ON_QW);
-    static const hipError_t attr = hipFuncSetAttribute((const void*)out_nb_fused_kernel,
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    if (attr != hipSuccess) return (int)attr;
     if (shm > 96 * 1024) return -2;
-    hipLaunchKernelGGL(out_nb_fused_kernel, dim3((B + ON_ROWS - 1) / ON_ROWS), dim3(ON_T), shm, (hipStream_t)stream, a);
+    const dim3 grid((B + ON_ROWS - 1) / ON_ROWS), block(ON_T);
+    hipStream_t st = (hipStream_t)stream;
+#define ON_LAUNCH(CPP)                                                                                              \
+    do {                                                                                                            \
+        static const hipError_t attr = hipFuncSetAttribute((const void*)out_nb_fused_kernel<CPP>,                    \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);  \
+        if (attr != hipSuccess) return (int)attr;                                                                   \
+        hipLaunchKernelGGL(out_nb_fused_kernel<CPP>, grid, block, shm, st, a);                                      \
+    } while (0)
+    if (K == 32) ON_LAUNCH(1);
+    else if (K == 64) ON_LAUNCH(2);
+    else if (K == 128) ON_LAUNCH(4);
+    else ON_LAUNCH(8);
+#undef ON_LAUNCH
     SCA_CHECK_LAUNCH();
     return 0;
 }

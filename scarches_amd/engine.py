@@ -442,6 +442,15 @@ class CVAEEngine:
                 if k.startswith("l_encoder."):
                     self.trainable[k] = False
 
+    def _out_fused_ok(self):
+        """Output layer + NB likelihood as ONE launch (csrc/out_nb_fused.hip): the fused trVAE step with the plain NB
+        head on a CSR matrix, shapes the kernel holds in registers (G <= 2048, last hidden width a multiple of 16)."""
+        # OPT-IN (SCA_OUT_FUSED=1): parity-green, but measured slower than the GEMM + likelihood pair on MI355X
+        # (246 vs 177 us alone at 8192 cells, DESIGN.md section 3)
+        return bool(os.environ.get("SCA_OUT_FUSED", "0") == "1"
+                    and self.use_fused_mid and self.recon == "nb" and self.arch == "trvae" and self.out_w is not None
+                    and self.lib.sca_out_nb_fused_supported(self.G, self.dec[-1].n_out))
+
     # ------------------------------------------------------------------------------------------ workspaces
     def _invalidate(self):
         """Drop everything that holds raw workspace addresses (recorded launch plans, HIP graphs, cached kernel
@@ -483,6 +492,9 @@ class CVAEEngine:
         ws["logits"] = torch.empty(B, G, dtype=f32, device=dev)
         if self.recon == "zinb":
             ws["pi"] = torch.empty(B, G, dtype=f32, device=dev)
+        if self._out_fused_ok():
+            ws["gam_tab"] = torch.empty(C, G, 17, 2, dtype=f32, device=dev)
+            ws["ext_ovf"] = torch.empty(B, G, dtype=f32, device=dev)      # touched only by cells with > 512 counts
         ws["tab_theta"] = torch.empty(C, G, dtype=f32, device=dev)
         ws["tab_lte"] = torch.empty(C, G, dtype=f32, device=dev)
         ws["dthetaT"] = torch.empty(C, G, dtype=f32, device=dev)
@@ -1033,6 +1045,9 @@ class CVAEEngine:
             if self.has_theta:
                 _lib.check(L.sca_theta_prep(P["theta"].data_ptr(), G, C, ws["tab_theta"].data_ptr(),
                                             ws["tab_lte"].data_ptr(), sa), "theta_prep")
+                if "gam_tab" in ws:
+                    _lib.check(L.sca_nb_gamma_table(ws["tab_theta"].data_ptr(), C, G, ws["gam_tab"].data_ptr(), sa),
+                               "nb_gamma_table")
                 if compute_grad:
                     self._zero(ws["dthetaT"], sa)
             if compute_grad:
@@ -1296,38 +1311,55 @@ class CVAEEngine:
         ev_side = None if after_out else self._flush()
         Hd = self.dec[-1].n_out
         h_last = ws[self.dec[-1].tag + ".h"].data_ptr()
-        if after_out:
-            self._wait(self._ev_pro)
-        self._gemm(0, 0, h_last, Hd, P[self.out_w].data_ptr(), Hd, B, G, Hd, st, out=ws["logits"].data_ptr(), ldc=G,
-                   bias=P[self.out_b].data_ptr(), force_s1=True)
-        if after_out:
-            self._defer(mmd_work)
+        out_fused = "gam_tab" in ws and self.csr is not None and not mmd_split
         ev_mmd2 = None
-        if mmd_split:
-            ev_mmd2 = self._next_event()
-
-            def mmd_work2(sa):
-                self._mmd_launch(sa, ws["z"], Z, self._cond_cur, cond_p, B, compute_grad, rows=(n1, B - n1), part_off=nA)
-                self._call(ev_mmd2.record, self._lane_stream(0))
-        # (measured: with this wait moved in front of the output GEMM - to spare the stream operation between the GEMM
-        #  and the likelihood kernel - the GEMM is dispatched behind the MMD, which then holds every CU: 0.665 -> 0.753 ms;
-        #  in front of the MMD's fork event, so that the MMD is not ahead of the GEMM: +4 us, twice)
-        if not after_out:
-            self._wait(self._ev_pro)
         rpb = _recon_rows_per_block(B)
         gob = self.g[self.out_b].data_ptr() if T[self.out_b] else None
-        if self.recon == "mse":
-            _lib.check(L.sca_mse_rows(ws["logits"].data_ptr(), G, ws["x"].data_ptr(), G, B, G, rpb,
-                                      ws["row_ll"].data_ptr(), gob, int(compute_grad), 1, None, None, st), "mse_rows")
-            recon_sign = 1.0
-        else:
+        if out_fused:
+            # ONE launch: logits by MFMA into registers, softmax + likelihood + backward from there, only d-logits
+            # written.  It needs the theta / gamma tables and the zeroed accumulators of the prologue.
+            self._wait(self._ev_pro)
+            if after_out:
+                self._defer(mmd_work)
             ip, ix, dv = self.csr
-            _lib.check(L.sca_recon_rows(0, ws["logits"].data_ptr(), G, None, ip.data_ptr(), ix.data_ptr(),
-                                        dv.data_ptr(), ptr(row_ids), ws["sf"].data_ptr(), cond_p,
-                                        ws["tab_theta"].data_ptr(), ws["tab_lte"].data_ptr(), B, G, max(C, 1), rpb,
-                                        ws["row_ll"].data_ptr(), ws["dthetaT"].data_ptr(), gob, None,
-                                        int(compute_grad), None, None, st), "recon_rows")
+            _lib.check(L.sca_out_nb_fused(h_last, Hd, P[self.out_w].data_ptr(), Hd, P[self.out_b].data_ptr(),
+                                          ip.data_ptr(), ix.data_ptr(), dv.data_ptr(), ptr(row_ids),
+                                          ws["sf"].data_ptr(), cond_p, ws["tab_theta"].data_ptr(),
+                                          ws["gam_tab"].data_ptr(), B, G, Hd, max(C, 1), ws["logits"].data_ptr(), G,
+                                          ws["ext_ovf"].data_ptr(), G, ws["row_ll"].data_ptr(),
+                                          ws["dthetaT"].data_ptr(), gob, int(compute_grad), st), "out_nb_fused")
             recon_sign = -1.0
+        else:
+            if after_out:
+                self._wait(self._ev_pro)
+            self._gemm(0, 0, h_last, Hd, P[self.out_w].data_ptr(), Hd, B, G, Hd, st, out=ws["logits"].data_ptr(), ldc=G,
+                       bias=P[self.out_b].data_ptr(), force_s1=True)
+            if after_out:
+                self._defer(mmd_work)
+            ev_mmd2 = None
+            if mmd_split:
+                ev_mmd2 = self._next_event()
+
+                def mmd_work2(sa):
+                    self._mmd_launch(sa, ws["z"], Z, self._cond_cur, cond_p, B, compute_grad, rows=(n1, B - n1), part_off=nA)
+                    self._call(ev_mmd2.record, self._lane_stream(0))
+            # (measured: with this wait moved in front of the output GEMM - to spare the stream operation between the GEMM
+            #  and the likelihood kernel - the GEMM is dispatched behind the MMD, which then holds every CU: 0.665 -> 0.753 ms;
+            #  in front of the MMD's fork event, so that the MMD is not ahead of the GEMM: +4 us, twice)
+            if not after_out:
+                self._wait(self._ev_pro)
+            if self.recon == "mse":
+                _lib.check(L.sca_mse_rows(ws["logits"].data_ptr(), G, ws["x"].data_ptr(), G, B, G, rpb,
+                                          ws["row_ll"].data_ptr(), gob, int(compute_grad), 1, None, None, st), "mse_rows")
+                recon_sign = 1.0
+            else:
+                ip, ix, dv = self.csr
+                _lib.check(L.sca_recon_rows(0, ws["logits"].data_ptr(), G, None, ip.data_ptr(), ix.data_ptr(),
+                                            dv.data_ptr(), ptr(row_ids), ws["sf"].data_ptr(), cond_p,
+                                            ws["tab_theta"].data_ptr(), ws["tab_lte"].data_ptr(), B, G, max(C, 1), rpb,
+                                            ws["row_ll"].data_ptr(), ws["dthetaT"].data_ptr(), gob, None,
+                                            int(compute_grad), None, None, st), "recon_rows")
+                recon_sign = -1.0
         if after_out:
             ev_side = self._flush()
         if mmd_split:

@@ -101,12 +101,13 @@ def _ref64(d, B):
 
 
 CASES = [
-    dict(B=16, G=64, K=16, C=1, seed=1),
+    dict(B=16, G=64, K=32, C=1, seed=1),
     dict(B=37, G=200, K=32, C=3, seed=2, dense_rows=(5,), empty_rows=(0, 36)),
     dict(B=128, G=1000, K=128, C=5, seed=3, sorted_cond=False),
     dict(B=250, G=2000, K=128, C=20, seed=4, dense_rows=(17, 18, 249), empty_rows=(100,)),
     dict(B=96, G=2048, K=64, C=4, seed=5, big_theta=True),
-    dict(B=1, G=17, K=16, C=2, seed=6),
+    dict(B=1, G=17, K=32, C=2, seed=6),
+    dict(B=40, G=300, K=256, C=2, seed=7),
 ]
 
 
@@ -166,6 +167,7 @@ def test_out_nb_fused_row_ids_and_rejections():
         scale = u[k].abs().max().item() + 1e-30
         assert (f[k] - u[k]).abs().max().item() <= 2e-5 * scale, k
     assert lib.sca_out_nb_fused_supported(4000, 128) == 0 and lib.sca_out_nb_fused_supported(2000, 100) == 0
+    assert lib.sca_out_nb_fused_supported(2000, 16) == 0
     h = u["dev"][0]
     args = [h.data_ptr(), K, u["dev"][1].data_ptr(), K, u["dev"][2].data_ptr(), None, None, None, None, None, None,
             u["tab_theta"].data_ptr(), u["tab_theta"].data_ptr(), B, 4000, K, C, f["dl"].data_ptr(), 4000, None, 0,
