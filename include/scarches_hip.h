@@ -125,6 +125,14 @@ int sca_recon_rows(int zinb, float* logits, int ldl, float* pi, const int64_t* i
                    const float* tab_theta, const float* tab_lte, int B, int G, int C, int rows_per_block, float* row_ll,
                    float* dthetaT, float* dbias, float* dbias_pi, int compute_grad, const float* cond_off,
                    float* row_dsf, void* stream);
+/* sca_recon_rows with the per-step gamma-term table of sca_nb_gamma_table (gam_tab [C][G][17][2], NULL = none, then
+ * identical to sca_recon_rows): integer counts <= 16 look their lgamma / digamma differences up instead of running the
+ * per-count product loop (the table holds the results of that same loop, so values do not change). */
+int sca_recon_rows_tab(int zinb, float* logits, int ldl, float* pi, const int64_t* indptr, const int32_t* indices,
+                       const float* data, const int64_t* row_ids, const float* sizefactor, const int32_t* cond,
+                       const float* tab_theta, const float* tab_lte, int B, int G, int C, int rows_per_block,
+                       float* row_ll, float* dthetaT, float* dbias, float* dbias_pi, int compute_grad,
+                       const float* cond_off, float* row_dsf, const float* gam_tab, void* stream);
 
 /* ---- output layer fused with the NB likelihood (round 3) -------------------------------------------------------
  * sca_out_nb_fused = sca_gemm_f32 (logits = h W^T + bias; models/trvae/modules.py:179-181,207) + sca_recon_rows

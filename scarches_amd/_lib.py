@@ -81,6 +81,7 @@ SIGNATURES = {
     "sca_nb_gamma_table": [P, I, I, P, P],
     "sca_out_nb_fused_debug_stamps": [P],
     "sca_out_nb_fused": [P, I, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, P, I, P, I, P, P, P, I, P],
+    "sca_recon_rows_tab": [I, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, I, P, P, P, P],
     "sca_poisson_rows": [P, I, P, P, P, P, P, I, I, I, P, I, P],
     "sca_nb_elem_rows": [I, P, I, P, P, P, P, P, P, P, I, I, I, I, P, P, I, P, P],
     "sca_mse_rows": [P, I, P, I, I, I, I, P, P, I, I, P, P, P],

@@ -62,6 +62,8 @@ struct ReconArgs {
                                     // decoder.L0.cond_L, scarches/models/expimap/modules.py:83-84), transposed
     float* row_dsf;                 // optional [B]: d recon / d sizefactor_b (expiMap's library-size encoder makes the
                                     // size factor a function of the parameters, expimap.py:186-187)
+    const float2* gam_tab;          // optional [C][G][17]: (lgam, dig) of integer counts 0..16 per (condition, gene),
+                                    // sca_nb_gamma_table: replaces the per-count product loop of the fast path
 };
 
 // All loads of a register array issued before any of them is consumed: ONE asm statement names every element, so
@@ -218,13 +220,19 @@ __global__ __launch_bounds__(T, 4) void recon_rows_kernel(const ReconArgs a) {
 
         // ---- sparse phase: one lane per stored count of this row
         float ll = 0.f;
+        const float2* gt = a.gam_tab ? a.gam_tab + (long long)c * G * 17 : nullptr;
         auto stored = [&](int64_t k, float x, int g, float th, float lv) {
             if (!(x > NB_EPS)) return;
             const float mu = __expf(lv - mx) * inv * s;
             const float den = th + mu + NB_EPS;
             const float L = fast_logf(den), rr = __builtin_amdgcn_rcpf(den);
             float lgam = 0.f, dig = 0.f;
-            if (nb_gamma_fast_ok(x, th)) {
+            if (gt && nb_gamma_fast_ok(x, th)) {
+                // the same product / harmonic forms, evaluated once per (condition, gene, count) and step
+                const float2 tv = gt[(long long)g * 17 + (int)x];
+                lgam = tv.x;
+                dig = tv.y;
+            } else if (nb_gamma_fast_ok(x, th)) {
                 // prod_k (theta+k) and sum_k 1/(theta+k) = num/den built without divisions (three full-rate ops per
                 // term + the factorial alongside; theta < 128 keeps 16 factors inside fp32 range): ONE rcp per count
                 const int n = min((int)x, 16);
@@ -598,21 +606,35 @@ extern "C" int sca_transpose_scale(const float* src, int rows, int cols, float s
     return 0;
 }
 
+// sca_recon_rows with the gamma-term table of sca_nb_gamma_table (gam_tab [C][G][17][2], NULL = none): integer counts
+// <= 16 read their (lgamma, digamma) differences instead of running the per-count product loop.
+extern "C" int sca_recon_rows_tab(int zinb, float* logits, int ldl, float* pi, const int64_t* indptr,
+                                  const int32_t* indices, const float* data, const int64_t* row_ids,
+                                  const float* sizefactor, const int32_t* cond, const float* tab_theta,
+                                  const float* tab_lte, int B, int G, int C, int rows_per_block, float* row_ll,
+                                  float* dthetaT, float* dbias, float* dbias_pi, int compute_grad,
+                                  const float* cond_off, float* row_dsf, const float* gam_tab, void* stream) {
+    if (B <= 0) return 0;
+    if (rows_per_block < 1 || ldl < G) return -1;
+    if (cond_off && !cond) return -1;
+    ReconArgs a{logits, ldl, pi, indptr, indices, data, row_ids, sizefactor, cond, tab_theta, tab_lte,
+                B, G, C, rows_per_block, row_ll, dthetaT, dbias, dbias_pi, compute_grad, cond_off, row_dsf,
+                reinterpret_cast<const float2*>(gam_tab)};
+    const int rc = zinb ? launch_recon<true>(a, (hipStream_t)stream) : launch_recon<false>(a, (hipStream_t)stream);
+    if (rc) return rc;
+    SCA_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int sca_recon_rows(int zinb, float* logits, int ldl, float* pi, const int64_t* indptr,
                               const int32_t* indices, const float* data, const int64_t* row_ids,
                               const float* sizefactor, const int32_t* cond, const float* tab_theta,
                               const float* tab_lte, int B, int G, int C, int rows_per_block, float* row_ll,
                               float* dthetaT, float* dbias, float* dbias_pi, int compute_grad,
                               const float* cond_off, float* row_dsf, void* stream) {
-    if (B <= 0) return 0;
-    if (rows_per_block < 1 || ldl < G) return -1;
-    if (cond_off && !cond) return -1;
-    ReconArgs a{logits, ldl, pi, indptr, indices, data, row_ids, sizefactor, cond, tab_theta, tab_lte,
-                B, G, C, rows_per_block, row_ll, dthetaT, dbias, dbias_pi, compute_grad, cond_off, row_dsf};
-    const int rc = zinb ? launch_recon<true>(a, (hipStream_t)stream) : launch_recon<false>(a, (hipStream_t)stream);
-    if (rc) return rc;
-    SCA_CHECK_LAUNCH();
-    return 0;
+    return sca_recon_rows_tab(zinb, logits, ldl, pi, indptr, indices, data, row_ids, sizefactor, cond, tab_theta,
+                              tab_lte, B, G, C, rows_per_block, row_ll, dthetaT, dbias, dbias_pi, compute_grad,
+                              cond_off, row_dsf, nullptr, stream);
 }
 
 extern "C" int sca_nb_elem_rows(int act, float* lin, int ldl, const int64_t* indptr, const int32_t* indices,
@@ -625,7 +647,7 @@ extern "C" int sca_nb_elem_rows(int act, float* lin, int ldl, const int64_t* ind
     const size_t shm = (size_t)2 * G * sizeof(float);
     if (shm > 150 * 1024) return -2;
     ReconArgs a{lin, ldl, nullptr, indptr, indices, data, row_ids, nullptr, cond, tab_theta, tab_lte,
-                B, G, C, rows_per_block, row_ll, dthetaT, nullptr, nullptr, compute_grad, cond_off, nullptr};
+                B, G, C, rows_per_block, row_ll, dthetaT, nullptr, nullptr, compute_grad, cond_off, nullptr, nullptr};
     if (shm > 48 * 1024)
         hipFuncSetAttribute((const void*)nb_elem_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     hipLaunchKernelGGL(nb_elem_rows_kernel, dim3((B + rows_per_block - 1) / rows_per_block), dim3(256), shm,

@@ -492,8 +492,14 @@ class CVAEEngine:
         ws["logits"] = torch.empty(B, G, dtype=f32, device=dev)
         if self.recon == "zinb":
             ws["pi"] = torch.empty(B, G, dtype=f32, device=dev)
-        if self._out_fused_ok():
+        if self.has_theta and C * G <= (1 << 22) and (os.environ.get("SCA_GAMMA_TABLE", "0") == "1"
+                                                      or self._out_fused_ok()):
+            # (lgamma, digamma) differences of integer counts <= 16 per (condition, gene), rebuilt with the theta tables.
+            # OPT-IN for the row kernel (SCA_GAMMA_TABLE=1): measured inside the cfg2 step the scattered reads of the
+            # 5.4 MB table cost more than the per-count product loop they replace (0.602 -> 0.616 ms at 8192 cells,
+            # 0.340 -> 0.347 at 4096); the fused output kernel needs the table.
             ws["gam_tab"] = torch.empty(C, G, 17, 2, dtype=f32, device=dev)
+        if self._out_fused_ok():
             ws["ext_ovf"] = torch.empty(B, G, dtype=f32, device=dev)      # touched only by cells with > 512 counts
         ws["tab_theta"] = torch.empty(C, G, dtype=f32, device=dev)
         ws["tab_lte"] = torch.empty(C, G, dtype=f32, device=dev)
@@ -1018,14 +1024,15 @@ class CVAEEngine:
             recon_sign = 1.0
         else:
             ip, ix, dv = self.csr
-            _lib.check(L.sca_recon_rows(int(zinb), ws["logits"].data_ptr(), G, ws["pi"].data_ptr() if zinb else None,
-                                        ip.data_ptr(), ix.data_ptr(), dv.data_ptr(), ptr(row_ids),
-                                        ws["sf"].data_ptr(), cond_p, ws["tab_theta"].data_ptr(),
-                                        ws["tab_lte"].data_ptr(), B, G, max(C, 1), rpb, ws["row_ll"].data_ptr(),
-                                        ws["dthetaT"].data_ptr(), gob,
-                                        self.g["decoder.dropout_decoder.bias"].data_ptr()
-                                        if zinb and self.trainable["decoder.dropout_decoder.bias"] else None,
-                                        int(compute_grad), None, None, st), "recon_rows")
+            _lib.check(L.sca_recon_rows_tab(int(zinb), ws["logits"].data_ptr(), G,
+                                            ws["pi"].data_ptr() if zinb else None,
+                                            ip.data_ptr(), ix.data_ptr(), dv.data_ptr(), ptr(row_ids),
+                                            ws["sf"].data_ptr(), cond_p, ws["tab_theta"].data_ptr(),
+                                            ws["tab_lte"].data_ptr(), B, G, max(C, 1), rpb, ws["row_ll"].data_ptr(),
+                                            ws["dthetaT"].data_ptr(), gob,
+                                            self.g["decoder.dropout_decoder.bias"].data_ptr()
+                                            if zinb and self.trainable["decoder.dropout_decoder.bias"] else None,
+                                            int(compute_grad), None, None, ptr(ws.get("gam_tab")), st), "recon_rows")
             recon_sign = -1.0
         self._defer_finalize(recon_sign, B, accumulate_logs)
         if not compute_grad:
@@ -1311,7 +1318,7 @@ class CVAEEngine:
         ev_side = None if after_out else self._flush()
         Hd = self.dec[-1].n_out
         h_last = ws[self.dec[-1].tag + ".h"].data_ptr()
-        out_fused = "gam_tab" in ws and self.csr is not None and not mmd_split
+        out_fused = "ext_ovf" in ws and "gam_tab" in ws and self.csr is not None and not mmd_split
         ev_mmd2 = None
         rpb = _recon_rows_per_block(B)
         gob = self.g[self.out_b].data_ptr() if T[self.out_b] else None
@@ -1354,11 +1361,12 @@ class CVAEEngine:
                 recon_sign = 1.0
             else:
                 ip, ix, dv = self.csr
-                _lib.check(L.sca_recon_rows(0, ws["logits"].data_ptr(), G, None, ip.data_ptr(), ix.data_ptr(),
-                                            dv.data_ptr(), ptr(row_ids), ws["sf"].data_ptr(), cond_p,
-                                            ws["tab_theta"].data_ptr(), ws["tab_lte"].data_ptr(), B, G, max(C, 1), rpb,
-                                            ws["row_ll"].data_ptr(), ws["dthetaT"].data_ptr(), gob, None,
-                                            int(compute_grad), None, None, st), "recon_rows")
+                _lib.check(L.sca_recon_rows_tab(0, ws["logits"].data_ptr(), G, None, ip.data_ptr(), ix.data_ptr(),
+                                                dv.data_ptr(), ptr(row_ids), ws["sf"].data_ptr(), cond_p,
+                                                ws["tab_theta"].data_ptr(), ws["tab_lte"].data_ptr(), B, G, max(C, 1),
+                                                rpb, ws["row_ll"].data_ptr(), ws["dthetaT"].data_ptr(), gob, None,
+                                                int(compute_grad), None, None, ptr(ws.get("gam_tab")), st),
+                           "recon_rows")
                 recon_sign = -1.0
         if after_out:
             ev_side = self._flush()
@@ -1582,12 +1590,13 @@ class CVAEEngine:
             recon_sign = -1.0
         else:
             ip, ix, dv = self.csr
-            _lib.check(L.sca_recon_rows(0, ws["logits"].data_ptr(), G, None, ip.data_ptr(), ix.data_ptr(),
-                                        dv.data_ptr(), ptr(row_ids), sf_p, cond_p,
-                                        ws["tab_theta"].data_ptr(), ws["tab_lte"].data_ptr(), B, G, max(C, 1), rpb,
-                                        ws["row_ll"].data_ptr(), ws["dthetaT"].data_ptr(), None, None,
-                                        int(compute_grad), coff,
-                                        ws["dsf"].data_ptr() if (lenc is not None and compute_grad) else None, st),
+            _lib.check(L.sca_recon_rows_tab(0, ws["logits"].data_ptr(), G, None, ip.data_ptr(), ix.data_ptr(),
+                                            dv.data_ptr(), ptr(row_ids), sf_p, cond_p,
+                                            ws["tab_theta"].data_ptr(), ws["tab_lte"].data_ptr(), B, G, max(C, 1), rpb,
+                                            ws["row_ll"].data_ptr(), ws["dthetaT"].data_ptr(), None, None,
+                                            int(compute_grad), coff,
+                                            ws["dsf"].data_ptr() if (lenc is not None and compute_grad) else None,
+                                            ptr(ws.get("gam_tab")), st),
                        "recon_rows")
             recon_sign = -1.0
         self._defer_finalize(recon_sign, B, accumulate_logs)

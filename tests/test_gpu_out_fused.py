@@ -173,3 +173,28 @@ def test_out_nb_fused_row_ids_and_rejections():
             u["tab_theta"].data_ptr(), u["tab_theta"].data_ptr(), B, 4000, K, C, f["dl"].data_ptr(), 4000, None, 0,
             f["row_ll"].data_ptr(), None, None, 0, None]
     assert lib.sca_out_nb_fused(*args) == -2
+
+
+def test_recon_rows_with_gamma_table_is_identical():
+    """sca_recon_rows_tab with the per-step table of sca_nb_gamma_table against sca_recon_rows: the table holds the
+    results of the same per-count loop, so losses and gradients agree to fp32 rounding."""
+    from scarches_amd import _lib
+    lib = _lib.load()
+    B, G, K, C = 200, 700, 32, 6
+    d = _case(B, G, K, C, seed=21, big_theta=True)
+    u = _unfused(lib, _lib, d, B, G, K, C)
+    h, W, bias, ip, ix, dv, sf, cond = u["dev"]
+    gam = torch.empty(C, G, 17, 2, device="cuda")
+    _lib.check(lib.sca_nb_gamma_table(u["tab_theta"].data_ptr(), C, G, gam.data_ptr(), None), "gamma_table")
+    tab_lte = torch.log(u["tab_theta"] + 1e-8)
+    logits = u["raw"].clone()
+    row_ll = torch.empty(B, device="cuda")
+    dthetaT, dbias = torch.zeros(C, G, device="cuda"), torch.zeros(G, device="cuda")
+    _lib.check(lib.sca_recon_rows_tab(0, logits.data_ptr(), G, None, ip.data_ptr(), ix.data_ptr(), dv.data_ptr(), None,
+                                      sf.data_ptr(), cond.data_ptr(), u["tab_theta"].data_ptr(), tab_lte.data_ptr(), B,
+                                      G, C, 4, row_ll.data_ptr(), dthetaT.data_ptr(), dbias.data_ptr(), None, 1, None,
+                                      None, gam.data_ptr(), None), "recon_rows_tab")
+    torch.cuda.synchronize()
+    # (same formulas; the two loops are compiled separately, so products may be contracted differently: last-bit noise)
+    for k, v in (("row_ll", row_ll), ("dl", logits), ("dthetaT", dthetaT), ("dbias", dbias)):
+        assert (v - u[k]).abs().max().item() <= 2e-6 * u[k].abs().max().item(), k
