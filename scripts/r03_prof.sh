@@ -7,7 +7,7 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 rm -rf "$OUT"
-timeout -k 10 240 rocprofv3 --kernel-trace --stats -d "$OUT" -- python3 bench.py --batch ${BATCH:-8192} --steps 30 --warmup 10 --no-cpu-baseline --no-sweep --no-loader-compare > gpurun_out/${TAG}_under_rocprof.json 2> gpurun_out/${TAG}_prof.err || { tail -5 gpurun_out/${TAG}_prof.err; exit 1; }
+timeout -k 10 240 rocprofv3 --kernel-trace --stats -d "$OUT" -- python3 bench.py --batch ${BATCH:-8192} --steps 30 --warmup 10 --no-cpu-baseline --no-sweep --no-loader-compare --no-families > gpurun_out/${TAG}_under_rocprof.json 2> gpurun_out/${TAG}_prof.err || { tail -5 gpurun_out/${TAG}_prof.err; exit 1; }
 DB=$(find "$OUT" -name '*.db' | head -1)
 python3 scripts/rocpd_export.py "$DB" gpurun_out/$TAG && rm -rf "$OUT"
 cat gpurun_out/${TAG}_step_timeline.txt
