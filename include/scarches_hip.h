@@ -300,6 +300,12 @@ typedef struct {
 int sca_mid_max_width(void);
 int sca_mid_fwd(const sca_mid_args* a, void* stream);
 int sca_mid_bwd(const sca_mid_args* a, void* stream);
+/* The same two passes through the first kernel family (weights staged through LDS in 32-deep chunks, 4 waves per
+ * 16-cell tile; fused_mid.hip).  sca_mid_fwd / sca_mid_bwd run the second family (fused_mid_direct.hip: MFMA weight
+ * fragments read straight from L2 with a re-labelled reduction index, 8 waves per tile, no barrier inside a GEMM) and
+ * route here when SCA_MID_DIRECT=0 is set in the environment; same arguments, same outputs (summation order aside). */
+int sca_mid_fwd_staged(const sca_mid_args* a, void* stream);
+int sca_mid_bwd_staged(const sca_mid_args* a, void* stream);
 
 /* ---- BatchNorm1d variant of the layer block (use_bn=True) -------------------------------------------------------
  * nn.BatchNorm1d(affine=True) between Linear and ReLU (models/trvae/modules.py:79,146,161).  sca_bn_fwd takes the

@@ -123,6 +123,8 @@ SIGNATURES = {
     "sca_mid_max_width": [],
     "sca_mid_fwd": [P, P],
     "sca_mid_bwd": [P, P],
+    "sca_mid_fwd_staged": [P, P],
+    "sca_mid_bwd_staged": [P, P],
     "sca_knn_max_k": [],
     "sca_knn_num_chunks": [I, I],
     "sca_knn_topk": [P, I, P, I, I, I, P, P, P, P, P],

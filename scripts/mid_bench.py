@@ -10,8 +10,24 @@ from scarches_amd.synth import make_synthetic_csr
 def phases(L, rf, st, tag):
     import ctypes
     try:
-        fn = L.sca_mid_debug
+        fn = L.sca_midd_debug
     except AttributeError:
+        return
+    if True:
+        buf = (ctypes.c_longlong * 64)()
+        L.sca_mid_fwd(rf, st); torch.cuda.synchronize()
+        L.sca_mid_bwd(RB[0], st); torch.cuda.synchronize()
+        fn(buf)
+        t = [buf[i] for i in range(64)]
+        names = ["prefetch", "first slabs", "first epilogue", "enc1 gemm", "enc1 epilogue", "heads gemm", "latent",
+                 "dec0 gemm", "dec0 epilogue", "dec1 gemm", "dec1 epilogue"]
+        marks = [t[15]] + t[0:11]
+        print(tag, "fwd phases (us):", {n: round((marks[i + 1] - marks[i]) / 100.0, 2) for i, n in enumerate(names)},
+              "total", round((marks[-1] - marks[0]) / 100.0, 2), flush=True)
+        bn = ["slabs in", "wait", "dec1 epi", "dec1 gemm", "dec0 epi", "dec0 gemm", "latent", "heads gemm", "enc1 epi", "enc1 gemm", "first epi"]
+        bm = t[32:44]
+        print(tag, "bwd phases (us):", {n: round((bm[i + 1] - bm[i]) / 100.0, 2) for i, n in enumerate(bn)},
+              "total", round((bm[-1] - bm[0]) / 100.0, 2), flush=True)
         return
     buf = (ctypes.c_longlong * 64)()
     L.sca_mid_fwd(rf, st); torch.cuda.synchronize()
@@ -29,12 +45,13 @@ def phases(L, rf, st, tag):
     print(tag, "fwd phases (us):", {n: round((marks[i + 1] - marks[i]) / 100.0, 2) for i, n in enumerate(names)},
           "total", round((marks[-1] - marks[0]) / 100.0, 2), flush=True)
 
+RB = []
 dev = torch.device("cuda", 0)
 G, C, Z, H = 2000, 20, 10, [128, 128]
 indptr, indices, data, cond_all, _ = make_synthetic_csr(50_000, G, C, dev, seed=1000)
 P = build_trvae_params(G, C, H, Z)
 gen = torch.Generator(device=dev); gen.manual_seed(1)
-for B in (128, 4096, 16384):
+for B in [int(x) for x in os.environ.get('MID_BS', '128,4096,16384').split(',')]:
     for p in (0.0, 0.05):
         spec = dict(G=G, C=C, H=H, Z=Z, recon="nb", use_bn=False, use_ln=True, use_mmd=True, mmd_on="z",
                     boundary=None, beta=1.0, dr_rate=p, seed=2020)
@@ -52,6 +69,7 @@ for B in (128, 4096, 16384):
         L = _lib.load()
         (af, rf), = [v for k, v in eng._mid_cache.items() if k[7] is None]
         (ab, rb), = [v for k, v in eng._mid_cache.items() if k[7] is not None]
+        RB[:] = [rb]
         for name, fn, ref in (("fwd", L.sca_mid_fwd, rf), ("bwd", L.sca_mid_bwd, rb)):
             for _ in range(3):
                 fn(ref, st)
