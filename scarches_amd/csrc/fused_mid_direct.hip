@@ -30,8 +30,10 @@ extern "C" int sca_mid_bwd_staged(const sca_mid_args* a, void* stream);
 #ifdef SCA_MID_DEBUG
 __device__ long long g_midd_dbg[64];
 #define DBG(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_midd_dbg[i] = wall_clock64(); } while (0)
+#define DBG_LAST(i) do { if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) g_midd_dbg[i] = wall_clock64(); } while (0)
 #else
 #define DBG(i)
+#define DBG_LAST(i)
 #endif
 
 namespace {
@@ -134,6 +136,79 @@ __device__ __forceinline__ void tile_gemm(const float* __restrict__ act, int lda
     __syncthreads();
 }
 
+// Fast path of the two above for the shapes that carry the time: reduction length exactly 128 (one super-chunk), at
+// most 128 output columns (one block per wave), 16-byte aligned weights.  Nothing is clamped but the output column,
+// every trip count is static: the 32 fragment loads are plain base + immediate-offset loads, all eight A reads are
+// issued before the first MFMA.
+__device__ __forceinline__ bool gemm_is_full(const float* W, int ldW, int I, int J) {
+    return I == SC && J <= 16 * NW && (ldW & 3) == 0 && (((uintptr_t)W) & 15) == 0;
+}
+
+template <bool FWD>
+__device__ __forceinline__ void bfrag_load_full(float (&b)[32], const float* __restrict__ W, int ldW, int J) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l16 = lane & 15, kg = lane >> 4;
+    const int j = min(16 * w + l16, J - 1);
+    if (FWD) {
+        const float* p = W + j * ldW + 4 * kg;                  // k = 16 i + 4 kg + u
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(p + 16 * i);
+            b[4 * i] = t.x; b[4 * i + 1] = t.y; b[4 * i + 2] = t.z; b[4 * i + 3] = t.w;
+        }
+    } else {
+        const float* p = W + 32 * kg * ldW + j;                 // k = 32 kg + s
+#pragma unroll
+        for (int s = 0; s < 32; ++s) b[s] = p[s * ldW];
+    }
+}
+
+template <bool FWD>
+__device__ __forceinline__ void tile_gemm_full(const float* __restrict__ act, int lda, int J, float* __restrict__ out,
+                                               int ldo, float (&bf)[32]) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l16 = lane & 15, kg = lane >> 4;
+    __syncthreads();                                 // `act` complete
+    if (16 * w < J) {
+        const float* ap = act + l16 * lda + (FWD ? 4 * kg : 32 * kg);
+        float4 av[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) av[i] = *reinterpret_cast<const float4*>(ap + (FWD ? 16 : 4) * i);
+        f32x4 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bf[4 * i], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bf[4 * i + 1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bf[4 * i + 2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bf[4 * i + 3], acc1, 0, 0, 0);
+        }
+        const int n = 16 * w + l16;
+        if (n < J) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[(4 * kg + r) * ldo + n] = acc0[r] + acc1[r];
+        }
+    }
+    __syncthreads();
+}
+
+// prefetch / product of GEMM (W, ldW, I, J), routed to the fast path where the shape allows it
+template <bool FWD>
+__device__ __forceinline__ void gemm_prefetch(float (&bf)[32], const float* __restrict__ W, int ldW, int I, int J) {
+    if (gemm_is_full(W, ldW, I, J)) {
+        bfrag_load_full<FWD>(bf, W, ldW, J);
+    } else {
+        const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        bfrag_load<FWD>(bf, W, ldW, I, J, w, 0, FWD && (I & 15) == 0 && (((uintptr_t)W) & 15) == 0);
+    }
+}
+
+template <bool FWD>
+__device__ __forceinline__ void gemm_run(const float* __restrict__ act, int lda, int I, const float* __restrict__ W,
+                                         int ldW, int J, float* __restrict__ out, int ldo, float (&bf)[32]) {
+    if (gemm_is_full(W, ldW, I, J)) tile_gemm_full<FWD>(act, lda, J, out, ldo, bf);
+    else tile_gemm<FWD>(act, lda, I, W, ldW, J, out, ldo, bf, FWD && (I & 15) == 0 && (((uintptr_t)W) & 15) == 0);
+}
+
 // 4 dropout keep decisions of columns col4 .. col4+3 (col4 % 4 == 0) from ONE Philox call - same bits as dropout_keep.
 __device__ __forceinline__ void dropout_keep4(uint64_t seed, uint32_t stream, uint32_t row, uint32_t col4, float p,
                                               bool (&k)[4]) {
@@ -171,19 +246,21 @@ __device__ __forceinline__ void load_tile(float* __restrict__ dst, int ld, const
                 off[i] = t < TM * w4 ? r * ld + k : -1;
                 v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            for (int q = 0; q < S; q += 4) {
-                float4 u[NP][4];
+            // SG slabs x NP positions of unconditional loads in flight (clamped slab index, a valid stand-in address
+            // for dead positions), summed in slab order; dead terms are dropped at the add
+            constexpr int SG = 8 / NP;
+            for (int q = 0; q < S; q += SG) {
+                float4 u[NP][SG];
 #pragma unroll
                 for (int i = 0; i < NP; ++i)
 #pragma unroll
-                    for (int h = 0; h < 4; ++h)
-                        u[i][h] = (p[i] && q + h < S) ? *reinterpret_cast<const float4*>(p[i] + (q + h) * stride)
-                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int h = 0; h < SG; ++h)
+                        u[i][h] = *reinterpret_cast<const float4*>((p[i] ? p[i] : src) + min(q + h, S - 1) * stride);
 #pragma unroll
                 for (int i = 0; i < NP; ++i)
 #pragma unroll
-                    for (int h = 0; h < 4; ++h)
-                        if (q + h < S) { v[i].x += u[i][h].x; v[i].y += u[i][h].y; v[i].z += u[i][h].z; v[i].w += u[i][h].w; }
+                    for (int h = 0; h < SG; ++h)
+                        if (p[i] && q + h < S) { v[i].x += u[i][h].x; v[i].y += u[i][h].y; v[i].z += u[i][h].z; v[i].w += u[i][h].w; }
             }
 #pragma unroll
             for (int i = 0; i < NP; ++i)
@@ -319,6 +396,82 @@ __device__ __forceinline__ bool fwd_vec(const float* W, int I) {
     return (I & 15) == 0 && (((uintptr_t)W) & 15) == 0;    // (forward: ldW == I)
 }
 
+// heads (tile `oth`: [mean | log_var] pre-bias) -> reparameterised sample + KL; z tile -> `cur`, zero padded
+__device__ __forceinline__ void latent_fwd_block(const sca_mid_args& a, float* __restrict__ oth, float* __restrict__ cur,
+                                                 int ld, int r0) {
+    const int Z = a.Z;
+    // heads -> reparameterised sample + KL
+    const int Zp = round_sc(Z);
+    const uint32_t stp = a.step ? a.step[0] : 0u;
+    for (int t = threadIdx.x; t < TM * (Zp - Z); t += NT) {          // zero padding of the z tile
+        const int r = t / (Zp - Z), k = Z + t - r * (Zp - Z);
+        cur[r * ld + k] = 0.f;
+    }
+    for (int t = threadIdx.x; t < TM * Z; t += NT) {
+        const int r = t / Z, k = t - r * Z, b = r0 + r;
+        float zv = 0.f, kl = 0.f;
+        if (b < a.B) {
+            const float mu = oth[r * ld + k] + a.bh[k], lv = oth[r * ld + Z + k] + a.bh[Z + k];
+            const float var = expf(lv) + 1e-4f, sd = sqrtf(var);
+            float e = 0.f;
+            if (a.sample) {
+                if (a.eps_in) {
+                    e = a.eps_in[(long long)b * Z + k];
+                } else {
+                    float n0, n1;
+                    philox_normal2(a.seed + stp, a.rng_latent, (uint32_t)(b * ((Z + 1) / 2) + (k >> 1)), n0, n1);
+                    e = (k & 1) ? n1 : n0;
+                }
+            }
+            const float vr = sd * sd;
+            kl = 0.5f * (vr + mu * mu - 1.0f - logf(vr));
+            a.mu_lv[(long long)b * 2 * Z + k] = mu;
+            a.mu_lv[(long long)b * 2 * Z + Z + k] = lv;
+            a.eps_out[(long long)b * Z + k] = e;
+            zv = fmaf(e, sd, mu);
+            a.z[(long long)b * Z + k] = zv;
+        }
+        cur[r * ld + k] = zv;
+        oth[r * ld + 2 * Z + k] = kl;                 // parked next to the head outputs, summed below
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < TM; r += NT)
+        if (r0 + r < a.B) {
+            float t = 0.f;
+            for (int k = 0; k < Z; ++k) t += oth[r * ld + 2 * Z + k];
+            a.kl_row[r0 + r] = t;
+        }
+    __syncthreads();
+}
+
+// latent block backward: dz tile `cur` (+ dz2) + KL -> d[mean | log_var] -> HBM and tile `oth`, zero padded
+__device__ __forceinline__ void latent_bwd_block(const sca_mid_args& a, const float* __restrict__ cur,
+                                                 float* __restrict__ oth, int ld, int r0) {
+    const int Z = a.Z;
+    // latent block: dz (+ dz2) + KL -> d[mean | log_var]
+    const float akl = a.hyper[0] / (float)a.B;
+    const int Hp = round_sc(2 * Z);
+    for (int t = threadIdx.x; t < TM * (Hp - 2 * Z); t += NT) {       // zero padding of the d-heads tile
+        const int r = t / (Hp - 2 * Z), k = 2 * Z + t - r * (Hp - 2 * Z);
+        oth[r * ld + k] = 0.f;
+    }
+    for (int t = threadIdx.x; t < TM * 2 * Z; t += NT) {
+        const int r = t / (2 * Z), k = t - r * 2 * Z, b = r0 + r;
+        float o = 0.f;
+        if (b < a.B) {
+            const int kk = k < Z ? k : k - Z;
+            float gz = cur[r * ld + kk];
+            if (a.dz2) gz += a.dz2[(long long)b * Z + kk];
+            const float mu = a.mu_lv[(long long)b * 2 * Z + kk], lv = a.mu_lv[(long long)b * 2 * Z + Z + kk];
+            const float ev = expf(lv), var = ev + 1e-4f, sd = sqrtf(var);
+            o = k < Z ? gz + akl * mu
+                      : gz * a.eps_out[(long long)b * Z + kk] * (0.5f * ev / sd) + akl * 0.5f * (1.0f - 1.0f / var) * ev;
+            a.dheads[(long long)b * 2 * Z + k] = o;
+        }
+        oth[r * ld + k] = o;
+    }
+}
+
 template <int NS>
 __global__ __launch_bounds__(NT, 4) void midd_fwd_kernel(const sca_mid_args a, int ld) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -342,13 +495,13 @@ __global__ __launch_bounds__(NT, 4) void midd_fwd_kernel(const sca_mid_args a, i
         const sca_mid_layer& L = g < a.n_enc ? a.enc[g] : a.dec[g - a.n_enc - 1];
         W = L.W; I = L.K; J = L.N;
     };
-    {
+    if (!a.fuse_first) {      // input tile (zero padded to a multiple of 128 columns), then the first GEMM's fragments
+        load_tile<NS>(A0, ld, a.h_in, 1, 0, r0, a.B, a.K0, round_sc(a.K0));
         const float* W; int I, J;
         gemm_ref(0, W, I, J);
-        bfrag_load<true>(wpre, W, I, I, J, wv, 0, fwd_vec(W, I));
+        gemm_prefetch<true>(wpre, W, I, I, J);
     }
-    if (!a.fuse_first)        // input tile (zero padded to a multiple of 128 columns)
-        load_tile<NS>(A0, ld, a.h_in, 1, 0, r0, a.B, a.K0, round_sc(a.K0));
+    // (fused first layer: its slab sum below runs with no fragment registers held; the g = -1 pass requests them)
     DBG(0);
     for (int g = a.fuse_first ? -1 : 0; g < ng; ++g) {
         const bool head = g == a.n_enc, first = g < 0;
@@ -362,59 +515,18 @@ __global__ __launch_bounds__(NT, 4) void midd_fwd_kernel(const sca_mid_args a, i
         } else {
             const float* W; int I, J;
             gemm_ref(g, W, I, J);
-            tile_gemm<true>(cur, ld, I, W, I, J, oth, ld, wpre, fwd_vec(W, I));
+            gemm_run<true>(cur, ld, I, W, I, J, oth, ld, wpre);
         }
         {
             const float* W; int I, J;
             gemm_ref(min(g + 1, ng - 1), W, I, J);           // (after the last GEMM: a harmless re-read)
-            bfrag_load<true>(wpre, W, I, I, J, wv, 0, fwd_vec(W, I));
+            gemm_prefetch<true>(wpre, W, I, I, J);
         }
         DBG(1 + 2 * (g + 1));
         if (!head) {
             layer_epilogue_fwd<NS>(a, L, oth, cur, ld, r0, epb, epc);
         } else {
-            // heads -> reparameterised sample + KL
-            const int Zp = round_sc(Z);
-            const uint32_t stp = a.step ? a.step[0] : 0u;
-            for (int t = threadIdx.x; t < TM * (Zp - Z); t += NT) {          // zero padding of the z tile
-                const int r = t / (Zp - Z), k = Z + t - r * (Zp - Z);
-                cur[r * ld + k] = 0.f;
-            }
-            for (int t = threadIdx.x; t < TM * Z; t += NT) {
-                const int r = t / Z, k = t - r * Z, b = r0 + r;
-                float zv = 0.f, kl = 0.f;
-                if (b < a.B) {
-                    const float mu = oth[r * ld + k] + a.bh[k], lv = oth[r * ld + Z + k] + a.bh[Z + k];
-                    const float var = expf(lv) + 1e-4f, sd = sqrtf(var);
-                    float e = 0.f;
-                    if (a.sample) {
-                        if (a.eps_in) {
-                            e = a.eps_in[(long long)b * Z + k];
-                        } else {
-                            float n0, n1;
-                            philox_normal2(a.seed + stp, a.rng_latent, (uint32_t)(b * ((Z + 1) / 2) + (k >> 1)), n0, n1);
-                            e = (k & 1) ? n1 : n0;
-                        }
-                    }
-                    const float vr = sd * sd;
-                    kl = 0.5f * (vr + mu * mu - 1.0f - logf(vr));
-                    a.mu_lv[(long long)b * 2 * Z + k] = mu;
-                    a.mu_lv[(long long)b * 2 * Z + Z + k] = lv;
-                    a.eps_out[(long long)b * Z + k] = e;
-                    zv = fmaf(e, sd, mu);
-                    a.z[(long long)b * Z + k] = zv;
-                }
-                cur[r * ld + k] = zv;
-                oth[r * ld + 2 * Z + k] = kl;                 // parked next to the head outputs, summed below
-            }
-            __syncthreads();
-            for (int r = threadIdx.x; r < TM; r += NT)
-                if (r0 + r < a.B) {
-                    float t = 0.f;
-                    for (int k = 0; k < Z; ++k) t += oth[r * ld + 2 * Z + k];
-                    a.kl_row[r0 + r] = t;
-                }
-            __syncthreads();
+            latent_fwd_block(a, oth, cur, ld, r0);             // heads -> reparameterised sample + KL
         }
         DBG(2 + 2 * (g + 1));
     }
@@ -540,19 +652,21 @@ __global__ __launch_bounds__(NT, 4) void midd_bwd_kernel(const sca_mid_args a, i
         W = L.W; ldW = L.K; I = L.N; J = L.K;
     };
     {
-        const float* W; int ldW, I, J;
-        gemm_ref(ng - 1, W, ldW, I, J);
-        bfrag_load<false>(wpre, W, ldW, I, J, wv, 0, false);
         const bool none = ng - 1 == a.n_enc;                 // (the heads have no epilogue)
         const sca_mid_layer& L = none ? a.first : a.dec[a.n_dec - 1];
         epilogue_bwd_prefetch<NS>(a, L, none, r0, ypre, rspre);
     }
-    // upstream gradient tile: sum of the dX slabs of the output GEMM
+    // upstream gradient tile: sum of the dX slabs of the output GEMM (no fragment registers held meanwhile)
     {
         const int N = a.n_dec ? a.dec[a.n_dec - 1].N : Z;
         load_tile<NS>(A0, ld, a.dh, a.S, a.dh_stride, r0, a.B, N, a.n_dec ? N : round_sc(N));
-        __syncthreads();
     }
+    {
+        const float* W; int ldW, I, J;
+        gemm_ref(ng - 1, W, ldW, I, J);
+        gemm_prefetch<false>(wpre, W, ldW, I, J);
+    }
+    __syncthreads();
     float* cur = A0;
     float* oth = A1;
     DBG(33);
@@ -563,28 +677,7 @@ __global__ __launch_bounds__(NT, 4) void midd_bwd_kernel(const sca_mid_args a, i
             const sca_mid_layer& L = MIDD_LAYER(g);
             layer_epilogue_bwd<NS>(a, L, cur, oth, ld, r0, ypre, rspre);                // oth = da [TM][N]
         } else {
-            // latent block: dz (+ dz2) + KL -> d[mean | log_var]
-            const float akl = a.hyper[0] / (float)a.B;
-            const int Hp = round_sc(2 * Z);
-            for (int t = threadIdx.x; t < TM * (Hp - 2 * Z); t += NT) {       // zero padding of the d-heads tile
-                const int r = t / (Hp - 2 * Z), k = 2 * Z + t - r * (Hp - 2 * Z);
-                oth[r * ld + k] = 0.f;
-            }
-            for (int t = threadIdx.x; t < TM * 2 * Z; t += NT) {
-                const int r = t / (2 * Z), k = t - r * 2 * Z, b = r0 + r;
-                float o = 0.f;
-                if (b < a.B) {
-                    const int kk = k < Z ? k : k - Z;
-                    float gz = cur[r * ld + kk];
-                    if (a.dz2) gz += a.dz2[(long long)b * Z + kk];
-                    const float mu = a.mu_lv[(long long)b * 2 * Z + kk], lv = a.mu_lv[(long long)b * 2 * Z + Z + kk];
-                    const float ev = expf(lv), var = ev + 1e-4f, sd = sqrtf(var);
-                    o = k < Z ? gz + akl * mu
-                              : gz * a.eps_out[(long long)b * Z + kk] * (0.5f * ev / sd) + akl * 0.5f * (1.0f - 1.0f / var) * ev;
-                    a.dheads[(long long)b * 2 * Z + k] = o;
-                }
-                oth[r * ld + k] = o;
-            }
+            latent_bwd_block(a, cur, oth, ld, r0);             // dz (+ dz2) + KL -> d[mean | log_var]
             // tile_gemm starts with a barrier
         }
         DBG(35 + 2 * (ng - 1 - g));
@@ -600,9 +693,9 @@ __global__ __launch_bounds__(NT, 4) void midd_bwd_kernel(const sca_mid_args a, i
         {
             const float* W; int ldW, I, J;
             gemm_ref(g, W, ldW, I, J);
-            tile_gemm<false>(oth, ld, I, W, ldW, J, cur, ld, wpre, false);    // cur = dX [TM][K]
+            gemm_run<false>(oth, ld, I, W, ldW, J, cur, ld, wpre);    // cur = dX [TM][K]
             gemm_ref(max(g - 1, 0), W, ldW, I, J);                            // (after the last GEMM: a harmless re-read)
-            bfrag_load<false>(wpre, W, ldW, I, J, wv, 0, false);
+            gemm_prefetch<false>(wpre, W, ldW, I, J);
         }
     }
 #undef MIDD_LAYER
@@ -620,6 +713,189 @@ __global__ __launch_bounds__(NT, 4) void midd_bwd_kernel(const sca_mid_args a, i
             if (r0 + r < a.B) a.dh_out[(long long)(r0 + r) * a.K0 + k] = cur[r * ld + k];
         }
     }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Straight-line kernels for the architecture that carries the benchmark (and the reference's tutorials): every hidden
+// width 128, fused first-layer epilogue, Z <= 16.  Same functions as the generic kernels above, but the chain is
+// written out - first-layer epilogue; encoder layers; heads + latent block; decoder layers - so every GEMM has static
+// trip counts, the fragment prefetch of the next GEMM is one fixed burst of loads per call site and the compiler's
+// counted waits survive (the generic loop selects layer, shape and path per pass: its waits degrade to vmcnt(0)
+// and its fragment registers are spilled around the epilogues).
+constexpr int LD128 = SC + 4;
+
+// sum of S slabs of a [TM][128] tile -> LDS; one 16-byte position per thread, eight slabs in flight
+__device__ __forceinline__ void load_tile128(float* __restrict__ dst, const float* __restrict__ src, int S, long long stride,
+                                             int r0, int B) {
+    const int r = threadIdx.x >> 5, k = (threadIdx.x & 31) * 4;
+    const bool live = r0 + r < B;
+    const float* p = src + (long long)min(r0 + r, B - 1) * SC + k;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < S; q += 8) {
+        float4 u[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) u[h] = *reinterpret_cast<const float4*>(p + min(q + h, S - 1) * stride);
+#pragma unroll
+        for (int h = 0; h < 8; ++h)
+            if (q + h < S) { v.x += u[h].x; v.y += u[h].y; v.z += u[h].z; v.w += u[h].w; }
+    }
+    if (!live) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(dst + r * LD128 + k) = v;
+}
+
+// fragments of a GEMM whose reduction is short (I <= 32: z -> first decoder layer forward, d-heads -> heads backward):
+// only lane group 0 carries data (k = s), the other groups meet zero activations and re-read the same rows
+template <bool FWD>
+__device__ __forceinline__ void bfrag_load_short(float (&b)[32], const float* __restrict__ W, int ldW, int I, int J) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l16 = lane & 15;
+    const int j = min(16 * w + l16, J - 1);
+    if (FWD) {
+        const float* p = W + j * ldW;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) b[s] = p[min(s, I - 1)];
+    } else {
+        const float* p = W + j;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) b[s] = p[min(s, I - 1) * ldW];
+    }
+}
+
+__global__ __launch_bounds__(NT, 4) void midd_fwd128_kernel(const sca_mid_args a) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * TM * LD128];
+    float* cur = smem;
+    float* oth = smem + TM * LD128;
+    constexpr int ld = LD128;
+    const int r0 = blockIdx.x * TM;
+    const int Z = a.Z;
+    __builtin_amdgcn_s_setprio(3);
+    warm_kernargs();
+    DBG(15);
+    DBG_LAST(16);
+    float wpre[32], epb[1][4], epc[1][4];
+    int mark = 0;
+    // first encoder layer: split-K slabs of its GEMM -> epilogue
+    epilogue_fwd_prefetch<1>(a, a.first, r0, epb, epc);
+    DBG(mark++);
+    load_tile128(oth, a.pre0, a.S0, a.pre0_stride, r0, a.B);
+    if (a.n_enc > 0) bfrag_load_full<true>(wpre, a.enc[0].W, SC, SC);
+    else bfrag_load_full<true>(wpre, a.Wh, SC, 2 * Z);
+    __syncthreads();
+    DBG(mark++);
+    layer_epilogue_fwd<1>(a, a.first, oth, cur, ld, r0, epb, epc);
+    DBG(mark++);
+    for (int l = 0; l < a.n_enc; ++l) {
+        const sca_mid_layer& L = a.enc[l];
+        epilogue_fwd_prefetch<1>(a, L, r0, epb, epc);
+        tile_gemm_full<true>(cur, ld, SC, oth, ld, wpre);
+        if (l + 1 < a.n_enc) bfrag_load_full<true>(wpre, a.enc[l + 1].W, SC, SC);
+        else bfrag_load_full<true>(wpre, a.Wh, SC, 2 * Z);
+        DBG(mark++);
+        layer_epilogue_fwd<1>(a, L, oth, cur, ld, r0, epb, epc);
+        DBG(mark++);
+    }
+    // heads -> sample + KL
+    tile_gemm_full<true>(cur, ld, 2 * Z, oth, ld, wpre);
+    bfrag_load_short<true>(wpre, a.dec[0].W, Z, Z, SC);
+    epilogue_fwd_prefetch<1>(a, a.dec[0], r0, epb, epc);
+    DBG(mark++);
+    latent_fwd_block(a, oth, cur, ld, r0);
+    DBG(mark++);
+    // decoder: z -> first layer (short reduction, labelling k = 32 kg + s), then 128 x 128 layers
+    tile_gemm_full<false>(cur, ld, SC, oth, ld, wpre);
+    if (a.n_dec > 1) bfrag_load_full<true>(wpre, a.dec[1].W, SC, SC);
+    DBG(mark++);
+    layer_epilogue_fwd<1>(a, a.dec[0], oth, cur, ld, r0, epb, epc);
+    DBG(mark++);
+    for (int l = 1; l < a.n_dec; ++l) {
+        const sca_mid_layer& L = a.dec[l];
+        epilogue_fwd_prefetch<1>(a, L, r0, epb, epc);
+        tile_gemm_full<true>(cur, ld, SC, oth, ld, wpre);
+        if (l + 1 < a.n_dec) bfrag_load_full<true>(wpre, a.dec[l + 1].W, SC, SC);
+        DBG(mark++);
+        layer_epilogue_fwd<1>(a, L, oth, cur, ld, r0, epb, epc);
+        DBG(mark++);
+    }
+    DBG_LAST(17);
+}
+
+__global__ __launch_bounds__(NT, 4) void midd_bwd128_kernel(const sca_mid_args a) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * TM * LD128];
+    float* cur = smem;
+    float* oth = smem + TM * LD128;
+    constexpr int ld = LD128;
+    const int r0 = blockIdx.x * TM;
+    const int Z = a.Z;
+    __builtin_amdgcn_s_setprio(3);
+    warm_kernargs();
+    DBG(32);
+    DBG_LAST(48);
+    float wpre[32], ypre[1][4], rspre = 0.f;
+    int mark = 33;
+    {
+        const sca_mid_layer& L = a.dec[a.n_dec - 1];
+        epilogue_bwd_prefetch<1>(a, L, false, r0, ypre, rspre);
+        load_tile128(cur, a.dh, a.S, a.dh_stride, r0, a.B);
+        bfrag_load_full<false>(wpre, L.W, L.K, L.K);          // dX = da W: 128 outputs reduced, L.K inputs (128 or Z)
+    }
+    __syncthreads();
+    DBG(mark++);
+    for (int l = a.n_dec - 1; l >= 0; --l) {
+        const sca_mid_layer& L = a.dec[l];
+        DBG(mark++);
+        layer_epilogue_bwd<1>(a, L, cur, oth, ld, r0, ypre, rspre);            // oth = da
+        DBG(mark++);
+        if (l > 0) epilogue_bwd_prefetch<1>(a, a.dec[l - 1], false, r0, ypre, rspre);
+        tile_gemm_full<false>(oth, ld, L.K, cur, ld, wpre);                    // cur = dX [TM][L.K]
+        if (l > 0) bfrag_load_full<false>(wpre, a.dec[l - 1].W, a.dec[l - 1].K, a.dec[l - 1].K);
+        else bfrag_load_short<false>(wpre, a.Wh, SC, 2 * Z, SC);
+    }
+    DBG(mark++);
+    latent_bwd_block(a, cur, oth, ld, r0);                                     // oth = d[mean | log_var], zero padded
+    DBG(mark++);
+    if (a.n_enc > 0) epilogue_bwd_prefetch<1>(a, a.enc[a.n_enc - 1], false, r0, ypre, rspre);
+    else epilogue_bwd_prefetch<1>(a, a.first, false, r0, ypre, rspre);
+    tile_gemm_full<false>(oth, ld, SC, cur, ld, wpre);                         // heads backward (short reduction)
+    if (a.n_enc > 0) bfrag_load_full<false>(wpre, a.enc[a.n_enc - 1].W, SC, SC);
+    for (int l = a.n_enc - 1; l >= 0; --l) {
+        const sca_mid_layer& L = a.enc[l];
+        DBG(mark++);
+        layer_epilogue_bwd<1>(a, L, cur, oth, ld, r0, ypre, rspre);
+        DBG(mark++);
+        if (l > 0) epilogue_bwd_prefetch<1>(a, a.enc[l - 1], false, r0, ypre, rspre);
+        else epilogue_bwd_prefetch<1>(a, a.first, false, r0, ypre, rspre);
+        tile_gemm_full<false>(oth, ld, SC, cur, ld, wpre);
+        if (l > 0) bfrag_load_full<false>(wpre, a.enc[l - 1].W, SC, SC);
+    }
+    DBG(mark++);
+    layer_epilogue_bwd<1>(a, a.first, cur, oth, ld, r0, ypre, rspre);          // da of the first layer feeds its dW GEMM
+    DBG(mark++);
+    DBG_LAST(49);
+}
+
+// shapes the straight-line kernels take
+bool is_128(const sca_mid_args* a) {
+    auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+    if (!a->fuse_first || a->K0 != SC || a->Kh != SC || a->Z < 1 || a->Z > 16 || a->n_dec < 1 || !a->pre0) return false;
+    if (a->first.N != SC || (a->pre0_stride & 3) || !al(a->pre0) || !al(a->Wh)) return false;
+    if (!al(a->first.yn) || !al(a->first.h)) return false;
+    for (int l = 0; l < a->n_enc; ++l) {
+        const sca_mid_layer& L = a->enc[l];
+        if (L.N != SC || L.K != SC || !al(L.W) || !al(L.yn) || !al(L.h)) return false;
+    }
+    for (int l = 0; l < a->n_dec; ++l) {
+        const sca_mid_layer& L = a->dec[l];
+        if (L.N != SC || L.K != (l ? SC : a->Z) || !al(L.W) || !al(L.yn) || !al(L.h)) return false;
+    }
+    return true;
+}
+
+bool is_128_bwd(const sca_mid_args* a) {
+    auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+    if (!is_128(a) || !a->dh || (a->dh_stride & 3) || !al(a->dh) || !al(a->first.da)) return false;
+    for (int l = 0; l < a->n_enc; ++l) if (!al(a->enc[l].da)) return false;
+    for (int l = 0; l < a->n_dec; ++l) if (!al(a->dec[l].da)) return false;
+    return true;
 }
 
 int check_and_ld(const sca_mid_args* a, int* ld, size_t* shm, int* wide) {
@@ -653,7 +929,7 @@ int check_and_ld(const sca_mid_args* a, int* ld, size_t* shm, int* wide) {
 int direct_mask() {
     static const int v = [] {
         const char* e = getenv("SCA_MID_DIRECT");
-        return e ? atoi(e) : 2;      // backward only: the forward pass of this family is slower at 8192 cells
+        return e ? atoi(e) : 3;
     }();
     return v;
 }
@@ -675,7 +951,9 @@ extern "C" int sca_mid_fwd(const sca_mid_args* a, void* stream) {
     if (rc == 2) return sca_mid_fwd_staged(a, stream);
     if (rc) return rc > 0 ? 0 : rc;
     const dim3 grid((a->B + TM - 1) / TM);
-    if (wide) {
+    if (is_128(a)) {
+        hipLaunchKernelGGL(midd_fwd128_kernel, grid, dim3(NT), 0, (hipStream_t)stream, *a);
+    } else if (wide) {
         hipLaunchKernelGGL(midd_fwd_kernel<2>, grid, dim3(NT), shm, (hipStream_t)stream, *a, ld);
     } else {
         hipLaunchKernelGGL(midd_fwd_kernel<1>, grid, dim3(NT), shm, (hipStream_t)stream, *a, ld);
@@ -692,7 +970,9 @@ extern "C" int sca_mid_bwd(const sca_mid_args* a, void* stream) {
     if (rc) return rc > 0 ? 0 : rc;
     if (!a->dh || !a->dheads || !a->hyper || (!a->fuse_first && !a->dh_out)) return -1;
     const dim3 grid((a->B + TM - 1) / TM);
-    if (wide) {
+    if (is_128_bwd(a)) {
+        hipLaunchKernelGGL(midd_bwd128_kernel, grid, dim3(NT), 0, (hipStream_t)stream, *a);
+    } else if (wide) {
         hipLaunchKernelGGL(midd_bwd_kernel<2>, grid, dim3(NT), shm, (hipStream_t)stream, *a, ld);
     } else {
         hipLaunchKernelGGL(midd_bwd_kernel<1>, grid, dim3(NT), shm, (hipStream_t)stream, *a, ld);

@@ -24,6 +24,8 @@ def phases(L, rf, st, tag):
         marks = [t[15]] + t[0:11]
         print(tag, "fwd phases (us):", {n: round((marks[i + 1] - marks[i]) / 100.0, 2) for i, n in enumerate(names)},
               "total", round((marks[-1] - marks[0]) / 100.0, 2), flush=True)
+        print(tag, "last block: fwd start +%.2f us, end +%.2f us (block 0 ends +%.2f); bwd start +%.2f, end +%.2f (block 0 ends +%.2f)" % (
+            (t[16] - t[15]) / 100., (t[17] - t[15]) / 100., (t[10] - t[15]) / 100., (t[48] - t[32]) / 100., (t[49] - t[32]) / 100., (t[43] - t[32]) / 100.), flush=True)
         bn = ["slabs in", "wait", "dec1 epi", "dec1 gemm", "dec0 epi", "dec0 gemm", "latent", "heads gemm", "enc1 epi", "enc1 gemm", "first epi"]
         bm = t[32:44]
         print(tag, "bwd phases (us):", {n: round((bm[i + 1] - bm[i]) / 100.0, 2) for i, n in enumerate(bn)},
