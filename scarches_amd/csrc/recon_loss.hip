@@ -87,7 +87,7 @@ constexpr int QMAX = 1024;     // LDS queue of heavy entries per row (overflow i
 // (128 VGPRs: the cap spills the eight cached reciprocals of a thread - one scratch reload per element of the dense
 //  sweep.  Without it - 148 VGPRs, no spills - the kernel alone runs 114 us instead of 130 at 8192 cells, and the step
 //  0.643 ms instead of 0.596: beside three MMD waves per SIMD the wider workgroup is placed later still.)
-template <int T, int EPT, bool ZINB>
+template <int T, int EPT, bool ZINB, bool TAB = false>
 __global__ __launch_bounds__(T, 4) void recon_rows_kernel(const ReconArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* tx = lds;              // [G] per-row extras of t = mu dll/dmu at nnz (cleared by the owner when read)
@@ -220,14 +220,16 @@ __global__ __launch_bounds__(T, 4) void recon_rows_kernel(const ReconArgs a) {
 
         // ---- sparse phase: one lane per stored count of this row
         float ll = 0.f;
-        const float2* gt = a.gam_tab ? a.gam_tab + (long long)c * G * 17 : nullptr;
+        // (TAB: a separate instantiation - carried as a run-time option the table costs the plain kernel six more spilled
+        //  registers under its 128-VGPR cap: 125 -> 137 us alone at 8192 cells)
+        const float2* gt = TAB ? a.gam_tab + (long long)c * G * 17 : nullptr;
         auto stored = [&](int64_t k, float x, int g, float th, float lv) {
             if (!(x > NB_EPS)) return;
             const float mu = __expf(lv - mx) * inv * s;
             const float den = th + mu + NB_EPS;
             const float L = fast_logf(den), rr = __builtin_amdgcn_rcpf(den);
             float lgam = 0.f, dig = 0.f;
-            if (gt && nb_gamma_fast_ok(x, th)) {
+            if (TAB && nb_gamma_fast_ok(x, th)) {
                 // the same product / harmonic forms, evaluated once per (condition, gene, count) and step
                 const float2 tv = gt[(long long)g * 17 + (int)x];
                 lgam = tv.x;
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(256) void poisson_rows_kernel(float* __restrict__ l
     }
 }
 
-template <bool ZINB>
+template <bool ZINB, bool TAB = false>
 int launch_recon(const ReconArgs& a, hipStream_t st) {
     const int G = a.G;
     const size_t shm = (size_t)(ZINB ? 3 : 2) * G * sizeof(float);
@@ -573,9 +575,9 @@ int launch_recon(const ReconArgs& a, hipStream_t st) {
 #define RL(TT, EE)                                                                                         \
     do {                                                                                                   \
         if (shm > 48 * 1024)                                                                               \
-            hipFuncSetAttribute((const void*)recon_rows_kernel<TT, EE, ZINB>,                              \
+            hipFuncSetAttribute((const void*)recon_rows_kernel<TT, EE, ZINB, TAB>,                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                     \
-        hipLaunchKernelGGL((recon_rows_kernel<TT, EE, ZINB>), dim3(nblk), dim3(TT), shm, st, a);           \
+        hipLaunchKernelGGL((recon_rows_kernel<TT, EE, ZINB, TAB>), dim3(nblk), dim3(TT), shm, st, a);      \
     } while (0)
     if (G <= 256 * 4) RL(256, 4);
     else if (G <= 256 * 8) RL(256, 8);
@@ -620,7 +622,9 @@ extern "C" int sca_recon_rows_tab(int zinb, float* logits, int ldl, float* pi, c
     ReconArgs a{logits, ldl, pi, indptr, indices, data, row_ids, sizefactor, cond, tab_theta, tab_lte,
                 B, G, C, rows_per_block, row_ll, dthetaT, dbias, dbias_pi, compute_grad, cond_off, row_dsf,
                 reinterpret_cast<const float2*>(gam_tab)};
-    const int rc = zinb ? launch_recon<true>(a, (hipStream_t)stream) : launch_recon<false>(a, (hipStream_t)stream);
+    const int rc = zinb ? launch_recon<true>(a, (hipStream_t)stream)
+                        : (gam_tab ? launch_recon<false, true>(a, (hipStream_t)stream)
+                                   : launch_recon<false>(a, (hipStream_t)stream));
     if (rc) return rc;
     SCA_CHECK_LAUNCH();
     return 0;
