@@ -47,7 +47,7 @@ def parse():
                          "GPU fixed) or the reference's MMD over the global minibatch (all-gather of z; O(B_global^2) "
                          "per rank - meant for the reference's batch sizes, not for 8 x 8192 cells)")
     ap.add_argument("--launch", choices=["auto", "plan", "graph", "eager"], default="auto",
-                    help="recorded launch plan, HIP-graph replay, eager launches, or auto (graph for B <= 4096, plan above)")
+                    help="recorded launch plan, HIP-graph replay, eager launches, or auto (graph up to 8192 cells on one GPU, plan above and for N > 1)")
     return ap.parse_args()
 
 
@@ -559,7 +559,8 @@ def main():
     dt = run(B, a.steps, a.warmup)
     host_issue_ms = run.host_issue_s / a.steps * 1e3
     dt_in_step = None
-    if not a.no_prefetch and not a.no_loader_compare and world == 1:
+    if not a.no_prefetch and not a.no_loader_compare and world == 1 and not (
+            a.launch == "graph" or (a.launch == "auto" and B <= __import__("scarches_amd.engine", fromlist=["GRAPH_MAX_B"]).GRAPH_MAX_B)):
         # the same steps with every minibatch gathered at the head of its own step (no look-ahead): reported beside
         # the headline so that the loader's share is visible in the line itself
         run.in_step_loader = True
@@ -579,6 +580,9 @@ def main():
                  f"dp_mmd_{other}_ms_per_step": dt_other / a.steps * 1e3,
                  f"dp_mmd_{other}_cells_per_s": B * world * a.steps / dt_other}
 
+    from scarches_amd.engine import GRAPH_MAX_B
+    eff_launch = ({"plan": "plan", "graph": "graph", "eager": "eager"}.get(a.launch)
+                  or ("graph" if (B <= GRAPH_MAX_B and world == 1) else "plan"))
     out = {
         "metric": "train cells/sec (fwd+bwd+Adam) trVAE 2k-HVG", "value": value, "unit": "cells/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -587,7 +591,8 @@ def main():
                                f"{data.numel() / n_local:.0f} nnz/cell), {C} conditions, NB loss, MMD on z, hidden {H}, "
                                f"Z={Z}, dropout 0.05, Adam(eps 0.01, wd 0.04)",
                    "batch_per_gpu": B, "global_batch": B * world, "parallelism": f"dp{world}" if world > 1 else "single",
-                   "launch": a.launch, "loader": "in-step" if a.no_prefetch else "one minibatch ahead",
+                   "launch": a.launch, "launch_effective": eff_launch,
+                   "loader": "one minibatch ahead" if (eff_launch == "plan" and not a.no_prefetch) else "in-step",
                    "mmd": "single device" if world == 1 else
                           ("global minibatch (all-gather of z)" if a.dp_mmd == "exact" else "per-rank slice")},
         "final_losses": {"recon": losses[0], "kl": losses[1], "mmd": losses[2]},
@@ -672,6 +677,9 @@ def main():
                 out["roofline"]["frac_note"] = ("frac = the step's GEMM launches replayed alone; frac_in_step = the "
                                                 "same launches inside the running step (event pairs on their streams)")
             out["in_step_kernel_us"] = {k: {"launches": n, "avg_us": us} for k, (n, us) in sorted(in_step.items())}
+            out["in_step_from"] = ("the timed run's own launch plan" if eff_launch == "plan" else
+                                   "a launch plan of the same step recorded for this measurement (the timed run is "
+                                   + eff_launch + "-launched: no per-launch events possible inside it)")
             out["hbm_kernels"], out["valu_kernels"] = kernel_rates(eng, plan, B, G, data.numel() / n_local, in_step)
         if not a.no_sweep and world == 1:
             sweep = {}

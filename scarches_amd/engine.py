@@ -53,6 +53,8 @@ MMD_SPLIT_MIN = int(os.environ.get("SCA_MMD_SPLIT_MIN", 4096))
 MMD_SPLIT_FRAC = float(os.environ.get("SCA_MMD_SPLIT_FRAC", 0.0))
 MMD_AFTER_OUT = os.environ.get("SCA_MMD_AFTER_OUT", "auto")      # "0" / "1" / "auto": see _fused_path
 MMD_AFTER_OUT_MAX = int(os.environ.get("SCA_MMD_AFTER_OUT_MAX", 6144))
+MMD_AFTER_OUT_MAX_GRAPH = int(os.environ.get("SCA_MMD_AFTER_OUT_MAX_GRAPH", 8192))   # while a HIP graph is captured
+GRAPH_MAX_B = int(os.environ.get("SCA_GRAPH_MAX_B", 8192))      # train_step(use_graph="auto"): HIP graph up to here
 MMD_PAD, MMD_PAD_AFTER_OUT = 40000, 24000       # sca_mmd_reserve_lds per fork point (SCA_MMD_LDS_PAD overrides both)
 
 
@@ -1296,8 +1298,12 @@ class CVAEEngine:
         # 0.596 vs 0.605 ms; 16384: 1.38 vs 1.41).  The balance point moved when the likelihood kernel got faster
         # (DPP reductions, 146 -> 128 us alone): with the slower kernel the late fork won at 8192 cells (0.611 vs 0.632).
         # A first MMD row block beside the output GEMM and the rest forked behind it: 0.601-0.62 ms, dropped.
+        # Replayed as a HIP graph the late fork wins up to 8192 cells (round 3, 300-step runs: 6144 cells 0.452 -> 0.426 ms,
+        # 7168: 0.532 -> 0.495, 8192: 0.595 -> 0.568 - the graph executor submits the branch behind the likelihood kernel's
+        # predecessor without the plan's marker in front of it, and the graph has no look-ahead gather to lose).
+        after_max = MMD_AFTER_OUT_MAX_GRAPH if torch.cuda.is_current_stream_capturing() else MMD_AFTER_OUT_MAX
         after_out = (do_mmd and not mmd_split and compute_grad and self.overlap
-                     and (MMD_AFTER_OUT == "1" or (MMD_AFTER_OUT == "auto" and B <= MMD_AFTER_OUT_MAX)))
+                     and (MMD_AFTER_OUT == "1" or (MMD_AFTER_OUT == "auto" and B <= after_max)))
         if do_mmd:
             if mmd_split:
                 nA = L.sca_mmd_rows_num_partials(B, n1, Z)
@@ -1874,10 +1880,13 @@ class CVAEEngine:
         buffers, so the launch sequence of a given batch size never changes.  It is recorded once and then either
           * "plan" : re-issued from the recorded (function, arguments) list - no Python work per launch besides the
                      ctypes call itself, launches stay in the hand-ordered main-first sequence;
-                     "auto" for B > 4096 (the HIP-graph executor re-orders independent branches - it starts the MMD
-                     beside the likelihood kernel instead of beside the output GEMM: 0.84 vs 0.77 ms at B=8192);
+                     "auto" for B > 8192 and for every data-parallel step (10240 cells: 0.757 ms against 0.784 as a
+                     graph; the look-ahead loader below exists in this mode only);
           * True   : replayed as HIP graphs (one graph launch per step; best when launch-bound: 0.27 ms at B=128
-                     against 0.37 ms eager) - "auto" for B <= 4096 (0.46 ms at B=4096, where the plan is bimodal);
+                     against 0.37 ms eager) - "auto" for B <= 8192 on one GPU.  Round 3 (300-step runs, plan / graph):
+                     2048 cells 0.255 / 0.226 ms, 4096: 0.332 / 0.310, 6144: 0.438 / 0.426, 8192: 0.573 / 0.568 with
+                     the MMD forked behind the output GEMM inside graphs (_fused_path); the plan is host-bound up to
+                     ~5000 cells (0.25 - 0.33 ms of host time per step against 0.13 - 0.24 for a graph launch);
           * False  : launched eagerly through the normal Python path.
 
         `next_rows` (int64 device tensor, same size as `row_ids`): the row ids of the minibatch the NEXT call will
@@ -1889,7 +1898,7 @@ class CVAEEngine:
             # (world > 1: the gradient all-reduce is a host call between the two replayed halves of the step.  The
             # intermittent hangs of bench.py's two-rank one-GPU rehearsal came from ProcessGroupGloo's device-tensor
             # path, not from the launch mode: see distributed._host_staged.)
-            use_graph = True if (B <= 4096 and world <= 1) else "plan"
+            use_graph = True if (B <= GRAPH_MAX_B and world <= 1) else "plan"
         self._dp_world, self._dp_grad_weight = int(world), grad_weight
         if world > 1 and use_graph is True:
             use_graph = "plan"      # the all-reduce is a host call inside the recorded sequence (not graph-captured)
