@@ -339,6 +339,11 @@ int sca_masked_copy(const float* src, int lds, const float* mask, int ldm, float
                     void* stream);
 int sca_prox_l1(float* W, long long n, float alpha, const float* I, void* stream);
 int sca_prox_group_lasso(float* W, int rows, int cols, float alpha, const float* omega, void* stream);
+/* The same operator with the column sums of squares in a caller-owned workspace of `cols` floats (any contents on
+ * entry) instead of the library's file-scope array: no state in the library, so calls on different streams may overlap
+ * when their workspaces differ.  -1 without a workspace. */
+int sca_prox_group_lasso_ws(float* W, int rows, int cols, float alpha, const float* omega, float* colsq_ws,
+                            void* stream);
 long long sca_hsic_workspace_floats(int B);
 int sca_hsic_fwd_bwd(const float* z, int ld, int B, int D, const uint8_t* side, float sigma_a, float sigma_b,
                      float weight, float* work, double* loss_weighted, float* loss_raw, int accumulate, float* dz,

@@ -118,6 +118,7 @@ SIGNATURES = {
     "sca_masked_dw": [P, I, P, I, P, P, I, I, I, I, I, P, LL, P],
     "sca_prox_l1": [P, LL, F, P, P],
     "sca_prox_group_lasso": [P, I, I, F, P, P],
+    "sca_prox_group_lasso_ws": [P, I, I, F, P, P, P],
     "sca_hsic_workspace_floats": [I],
     "sca_hsic_fwd_bwd": [P, I, I, I, P, F, F, F, P, P, P, I, P, I, P],
     "sca_mid_max_width": [],

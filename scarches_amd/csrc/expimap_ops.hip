@@ -44,16 +44,21 @@ __global__ __launch_bounds__(256) void prox_l1_kernel(float* __restrict__ W, lon
 // 64-row tiles (one float atomic per column and tile), apply.  The column sums live in a file-scope device array
 // (kernels name it directly; the host never takes its address): calls that overlap on one GPU would race on it -
 // the engine issues its proximal steps on one stream.  Matrices with more columns take the one-launch kernel.
+// sca_prox_group_lasso_ws takes the column sums as a caller-owned workspace of `cols` floats instead (no library state:
+// calls on different streams may overlap when their workspaces differ).
 constexpr int PROX_MAX_COLS = 16384;
 constexpr int PROX_ROWS = 64;              // rows per tile of the accumulate / apply kernels
 __device__ float g_prox_colsq[PROX_MAX_COLS];
 
-__global__ __launch_bounds__(256) void prox_gl_clear_kernel(int cols) {
+__global__ __launch_bounds__(256) void prox_gl_clear_kernel(int cols, float* __restrict__ ws) {
+    float* colsq = ws ? ws : g_prox_colsq;
     const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c < cols) g_prox_colsq[c] = 0.f;
+    if (c < cols) colsq[c] = 0.f;
 }
 
-__global__ __launch_bounds__(256) void prox_gl_sumsq_kernel(const float* __restrict__ W, int rows, int cols) {
+__global__ __launch_bounds__(256) void prox_gl_sumsq_kernel(const float* __restrict__ W, int rows, int cols,
+                                                            float* __restrict__ ws) {
+    float* colsq = ws ? ws : g_prox_colsq;
     __shared__ float part[4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
@@ -67,16 +72,18 @@ __global__ __launch_bounds__(256) void prox_gl_sumsq_kernel(const float* __restr
         }
     part[ry][cx] = ss;
     __syncthreads();
-    if (ry == 0 && c < cols) atomicAdd(&g_prox_colsq[c], (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]));
+    if (ry == 0 && c < cols) atomicAdd(&colsq[c], (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]));
 }
 
 __global__ __launch_bounds__(256) void prox_gl_apply_kernel(float* __restrict__ W, int rows, int cols, float alpha,
-                                                            const float* __restrict__ omega) {
+                                                            const float* __restrict__ omega,
+                                                            const float* __restrict__ ws) {
+    const float* colsq = ws ? ws : g_prox_colsq;
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cx;
     if (c >= cols) return;
     const int r0 = blockIdx.y * PROX_ROWS, r1 = min(rows, r0 + PROX_ROWS);
-    const float norm = sqrtf(g_prox_colsq[c]);
+    const float norm = sqrtf(colsq[c]);
     const float coeff = alpha * (omega ? omega[c] : 1.f);
     const float keep = norm > coeff ? 1.f : 0.f;
     float s = norm / coeff;
@@ -249,20 +256,33 @@ extern "C" int sca_prox_l1(float* W, long long n, float alpha, const float* I, v
     return 0;
 }
 
-extern "C" int sca_prox_group_lasso(float* W, int rows, int cols, float alpha, const float* omega, void* stream) {
+static int prox_group_lasso_impl(float* W, int rows, int cols, float alpha, const float* omega, float* ws,
+                                 void* stream) {
     if (rows <= 0 || cols <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    if (cols <= PROX_MAX_COLS && rows > 4 * PROX_ROWS) {
+    if ((ws || cols <= PROX_MAX_COLS) && rows > 4 * PROX_ROWS) {
         const dim3 grid((cols + 63) / 64, (rows + PROX_ROWS - 1) / PROX_ROWS);
-        hipLaunchKernelGGL(prox_gl_clear_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, cols);
-        hipLaunchKernelGGL(prox_gl_sumsq_kernel, grid, dim3(256), 0, st, W, rows, cols);
-        hipLaunchKernelGGL(prox_gl_apply_kernel, grid, dim3(256), 0, st, W, rows, cols, alpha, omega);
+        hipLaunchKernelGGL(prox_gl_clear_kernel, dim3((cols + 255) / 256), dim3(256), 0, st, cols, ws);
+        hipLaunchKernelGGL(prox_gl_sumsq_kernel, grid, dim3(256), 0, st, W, rows, cols, ws);
+        hipLaunchKernelGGL(prox_gl_apply_kernel, grid, dim3(256), 0, st, W, rows, cols, alpha, omega, ws);
     } else {
         hipLaunchKernelGGL(prox_group_lasso_kernel, dim3((cols + 63) / 64), dim3(256), 0, st, W, rows, cols, alpha,
                            omega);
     }
     SCA_CHECK_LAUNCH();
     return 0;
+}
+
+extern "C" int sca_prox_group_lasso(float* W, int rows, int cols, float alpha, const float* omega, void* stream) {
+    return prox_group_lasso_impl(W, rows, cols, alpha, omega, nullptr, stream);
+}
+
+// The same operator with the column sums of squares in a caller-owned workspace of `cols` floats (any contents on
+// entry): nothing is kept in the library, so calls on different streams with different workspaces may overlap.
+extern "C" int sca_prox_group_lasso_ws(float* W, int rows, int cols, float alpha, const float* omega, float* colsq_ws,
+                                       void* stream) {
+    if (!colsq_ws) return -1;
+    return prox_group_lasso_impl(W, rows, cols, alpha, omega, colsq_ws, stream);
 }
 
 extern "C" long long sca_hsic_workspace_floats(int B) { return 2LL * B * B + 3LL * B + 8; }

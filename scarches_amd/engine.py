@@ -54,6 +54,7 @@ MMD_SPLIT_FRAC = float(os.environ.get("SCA_MMD_SPLIT_FRAC", 0.0))
 MMD_AFTER_OUT = os.environ.get("SCA_MMD_AFTER_OUT", "auto")      # "0" / "1" / "auto": see _fused_path
 MMD_AFTER_OUT_MAX = int(os.environ.get("SCA_MMD_AFTER_OUT_MAX", 6144))
 MMD_AFTER_OUT_MAX_GRAPH = int(os.environ.get("SCA_MMD_AFTER_OUT_MAX_GRAPH", 8192))   # while a HIP graph is captured
+GRAPH_PREFETCH = os.environ.get("SCA_GRAPH_PREFETCH", "0") == "1"     # look-ahead gather inside captured graphs too
 GRAPH_MAX_B = int(os.environ.get("SCA_GRAPH_MAX_B", 8192))      # train_step(use_graph="auto"): HIP graph up to here
 MMD_PAD, MMD_PAD_AFTER_OUT = 40000, 24000       # sca_mmd_reserve_lds per fork point (SCA_MMD_LDS_PAD overrides both)
 
@@ -1925,7 +1926,8 @@ class CVAEEngine:
         self._ensure(B)
         # (launch plans only: captured into a HIP graph the trailing gather costs more than the head gather it
         #  replaces - 0.350 -> 0.360 ms at 4096 cells, 0.239 -> 0.245 ms at 1024)
-        do_next = next_rows is not None and use_graph == "plan" and self._pf_possible(next_rows, B)
+        do_next = (next_rows is not None and (use_graph == "plan" or (use_graph is True and GRAPH_PREFETCH))
+                   and self._pf_possible(next_rows, B))
         if do_next and (self._rows_next is None or self._rows_next.numel() < B):
             torch.cuda.synchronize(self.device)
             self._rows_next = torch.zeros(max(B, self.Bcap), dtype=torch.int64, device=self.device)

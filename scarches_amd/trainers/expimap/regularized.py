@@ -31,8 +31,13 @@ class ProxGroupLasso:
         if self._omega is not None:
             om = self._omega = self._omega.to(W.device)
             assert om.numel() == W.shape[1]
-        _lib.check(_lib.load().sca_prox_group_lasso(W.data_ptr(), W.shape[0], W.shape[1], float(self._alpha),
-                                                    _lib.ptr(om), _stream(W)), "prox_group_lasso")
+        # column sums of squares in a workspace this operator owns (sca_prox_group_lasso keeps them in a file-scope
+        # array of the library: two operators on different streams would race on it)
+        ws = getattr(self, "_colsq", None)
+        if ws is None or ws.numel() < W.shape[1] or ws.device != W.device:
+            ws = self._colsq = torch.empty(W.shape[1], dtype=torch.float32, device=W.device)
+        _lib.check(_lib.load().sca_prox_group_lasso_ws(W.data_ptr(), W.shape[0], W.shape[1], float(self._alpha),
+                                                       _lib.ptr(om), ws.data_ptr(), _stream(W)), "prox_group_lasso")
         return W
 
 
