@@ -342,6 +342,7 @@ class CVAEEngine:
         # output-layer weight gradient beside the dX chain
         self.aux2 = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("SCA_AUX2_PRIO", "0")))
         self._lanes_used = set()
+        self._side_deps = set()
         self._events = [torch.cuda.Event() for _ in range(128)]
         self._ev_i = 0
         self._aux_q = []
@@ -670,7 +671,19 @@ class CVAEEngine:
                 if other != lane and other in self._lanes_used:
                     ev2 = self._next_event()
                     self._call(ev2.record, self._lane_stream(other))
-                    self._call(stream.wait_event, ev2)
+                    if (lane, other) in self._side_deps and torch.cuda.is_current_stream_capturing():
+                        # ROCm 7.2: hipStreamEndCapture segfaults when two FORKED streams of one capture wait for each
+                        # other in both directions (A waits for an event of B after B waited for one of A - acyclic and
+                        # legal; torch-only reproduction in scripts/dbg/capture_crash_repro.py, also through a third
+                        # stream, also without work in between).  The second direction goes through the origin stream.
+                        main = torch.cuda.current_stream(self.device)
+                        ev3 = self._next_event()
+                        self._call(main.wait_event, ev2)
+                        self._call(ev3.record, main)
+                        self._call(stream.wait_event, ev3)
+                    else:
+                        self._call(stream.wait_event, ev2)
+                    self._side_deps.add((other, lane))
             self._lanes_used.add(lane)
             fn(stream.cuda_stream)
         self._aux_q = []
@@ -935,6 +948,7 @@ class CVAEEngine:
 
         self._aux_q = []
         self._lanes_used = set()
+        self._side_deps = set()
         self._tail_jobs = []
         self._prologue(B, compute_grad)
         self._covs_cur = covs
@@ -1396,7 +1410,11 @@ class CVAEEngine:
                 _lib.check(L.sca_transpose_scale(ws["dthetaT"].data_ptr(), max(C, 1), G, -1.0 / B,
                                                  Gd["theta"].data_ptr(), sa), "transpose_scale")
         # own stream: starts right behind the likelihood kernel (same dependency point as the loss finalisation)
-        self._defer(recon_side, lane=1, reuse=not mmd_split)
+        # (late fork: the MMD is still running when the likelihood kernel ends; with SCA_OUT_DW_AFTER_MMD=1 this
+        #  weight-gradient GEMM - needed by the gradient tail only - waits for it, so that the dX GEMM, which the chain
+        #  needs, shares the chip with the MMD alone)
+        dw_after_mmd = after_out and do_mmd and not mmd_split and os.environ.get("SCA_OUT_DW_AFTER_MMD", "0") == "1"
+        self._defer(recon_side, lane=1, reuse=not mmd_split and not dw_after_mmd, join=(0,) if dw_after_mmd else ())
         if mmd_split:
             self._flush()                       # the second MMD block must be enqueued before mid_bwd can wait for it
         sp, S, stride = self._gemm(0, 1, dl, G, P[self.out_w].data_ptr(), Hd, B, Hd, G, st, max_split=self._mid_max_split)

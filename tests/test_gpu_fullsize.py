@@ -397,3 +397,22 @@ def test_mid_direct_family_matches_staged_family(Hx, Zx, Bx):
             scale = float(w.abs().max())
             err = float((got[k] - w).abs().max())
             assert err <= 1e-5 * scale + 1e-7, (k, err, scale)
+
+
+def test_captured_step_with_side_streams_waiting_for_each_other(data, monkeypatch):
+    """hipStreamEndCapture of this ROCm segfaults when two forked streams of one capture wait for each other in both
+    directions (scripts/dbg/capture_crash_repro.py).  SCA_OUT_DW_AFTER_MMD=1 makes the step contain exactly that (the
+    output layer's weight-gradient GEMM on the second side stream waits for the MMD on the first, the gradient tail on
+    the first later waits for that GEMM): the engine routes the second direction through the origin stream while a
+    graph is captured, and the captured step gives the trajectory of the plain one."""
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SCA_OUT_DW_AFTER_MMD", flag)
+        eng = make_engine(data)
+        for _ in range(3):
+            eng.train_step(data["rows"], data["cond"], B, 0.5, 1e-3, use_graph=True)
+        torch.cuda.synchronize()
+        outs.append((eng.losses.cpu().numpy().copy(), eng.flat_p.detach().clone()))
+    (la, pa), (lb, pb) = outs
+    assert np.all(np.abs(la[:3] - lb[:3]) <= 1e-5 * np.abs(lb[:3])), (la, lb)
+    assert float((pa - pb).abs().max()) <= 1e-5 * float(pb.abs().max())
