@@ -87,8 +87,8 @@ constexpr int QMAX = 1024;     // LDS queue of heavy entries per row (overflow i
 // (128 VGPRs: the cap spills the eight cached reciprocals of a thread - one scratch reload per element of the dense
 //  sweep.  Without it - 148 VGPRs, no spills - the kernel alone runs 114 us instead of 130 at 8192 cells, and the step
 //  0.643 ms instead of 0.596: beside three MMD waves per SIMD the wider workgroup is placed later still.)
-template <int T, int EPT, bool ZINB, bool TAB = false>
-__global__ __launch_bounds__(T, 4) void recon_rows_kernel(const ReconArgs a) {
+template <int T, int EPT, bool ZINB, bool TAB = false, int WPS = 4>
+__global__ __launch_bounds__(T, WPS) void recon_rows_kernel(const ReconArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* tx = lds;              // [G] per-row extras of t = mu dll/dmu at nnz (cleared by the owner when read)
     float* dx = lds + a.G;        // [G] theta-gradient extras, accumulated over the rows of a condition run
@@ -580,7 +580,21 @@ int launch_recon(const ReconArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((recon_rows_kernel<TT, EE, ZINB, TAB>), dim3(nblk), dim3(TT), shm, st, a);      \
     } while (0)
     if (G <= 256 * 4) RL(256, 4);
-    else if (G <= 256 * 8) RL(256, 8);
+    else if (G <= 256 * 8) {
+        // Three waves per SIMD, no register cap (148 VGPRs, nothing spilled; 114 us alone against 125 at 8192 cells):
+        // measured inside the cfg2 step (round 3, 300-step runs) it LOSES up to 8192 cells per step - 0.566 -> 0.578 ms
+        // at 8192, 0.425 -> 0.446 at 6144, 0.309 -> 0.311 at 4096: beside the MMD's waves the wider workgroups are
+        // placed later - and wins above - 1.305 -> 1.270 ms at 16384, where the likelihood kernel has the chip to
+        // itself for longer.  SCA_RECON_WIDE = 0 / 1 overrides the batch-size rule.
+        static const int wide_env = [] { const char* e = getenv("SCA_RECON_WIDE"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+        const bool wide = wide_env >= 0 ? wide_env == 1 : a.B >= 12288;
+        if (wide && !ZINB && !TAB) {
+            if (shm > 48 * 1024)
+                hipFuncSetAttribute((const void*)recon_rows_kernel<256, 8, false, false, 3>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+            hipLaunchKernelGGL((recon_rows_kernel<256, 8, false, false, 3>), dim3(nblk), dim3(256), shm, st, a);
+        } else RL(256, 8);
+    }
     else if (G <= 512 * 8) RL(512, 8);
     else if (G <= 1024 * 8) RL(1024, 8);
     else if (G <= 1024 * 12) RL(1024, 12);
