@@ -120,6 +120,11 @@ int sca_latent_bwd(const float* dz, int S, long long slab_stride, const float* d
  * CSR; d recon / d lin in place, theta gradients accumulated into dthetaT like sca_recon_rows.
  * sca_transpose_scale: dst[cols][rows] = scale * src[rows][cols] (dthetaT -> theta.grad layout [G][C]). */
 int sca_theta_prep(const float* theta, int G, int C, float* tab_theta, float* tab_lte, void* stream);
+/* sca_theta_prep plus two zero fills (dthetaT, the flat gradient buffer = optimizer.zero_grad(), trainer.py:272) in the
+ * same launch: the per-step prologue as one kernel.  zero0 / zero1 may be NULL; pointers 16-byte aligned, byte counts
+ * multiples of 16 (-1 otherwise).  G * C == 0 skips the tables. */
+int sca_theta_prep_zero(const float* theta, int G, int C, float* tab_theta, float* tab_lte, void* zero0,
+                        long long bytes0, void* zero1, long long bytes1, void* stream);
 int sca_recon_rows(int zinb, float* logits, int ldl, float* pi, const int64_t* indptr, const int32_t* indices,
                    const float* data, const int64_t* row_ids, const float* sizefactor, const int32_t* cond,
                    const float* tab_theta, const float* tab_lte, int B, int G, int C, int rows_per_block, float* row_ll,

@@ -76,6 +76,7 @@ SIGNATURES = {
     "sca_latent_fwd": [P, I, LL, P, I, I, P, U64, U32, P, I, P, P, P, P, P],
     "sca_latent_bwd": [P, I, LL, P, I, LL, P, P, P, I, I, P, P],
     "sca_theta_prep": [P, I, I, P, P, P],
+    "sca_theta_prep_zero": [P, I, I, P, P, P, LL, P, LL, P],
     "sca_recon_rows": [I, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, I, P, P, P],
     "sca_out_nb_fused_supported": [I, I],
     "sca_nb_gamma_table": [P, I, I, P, P],

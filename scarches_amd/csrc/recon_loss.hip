@@ -37,6 +37,26 @@ __global__ __launch_bounds__(256) void theta_prep_kernel(const float* __restrict
     tab_lte[i] = logf(th + NB_EPS);
 }
 
+// theta_prep_kernel + two zero fills (16-byte aligned, lengths in float4 units) in one launch: the prologue of a step
+// was three launches on a side stream (tables, dthetaT = 0, flat gradient buffer = 0) and, at small batch sizes, ended
+// after the encoder that the likelihood kernel waits behind.
+__global__ __launch_bounds__(256) void theta_prep_zero_kernel(const float* __restrict__ theta, int G, int C,
+                                                              float* __restrict__ tab_theta, float* __restrict__ tab_lte,
+                                                              float4* __restrict__ z0, long long n0,
+                                                              float4* __restrict__ z1, long long n1) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long stride = (long long)gridDim.x * 256;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long long k = i; k < n0; k += stride) z0[k] = zero;
+    for (long long k = i; k < n1; k += stride) z1[k] = zero;
+    for (long long k = i; k < (long long)G * C; k += stride) {
+        const int c = (int)(k / G), g = (int)(k - (long long)c * G);
+        const float th = expf(theta[(long long)g * C + c]);
+        tab_theta[k] = th;
+        tab_lte[k] = logf(th + NB_EPS);
+    }
+}
+
 // dtheta[g][c] = scale * dthetaT[c][g]
 __global__ __launch_bounds__(256) void transpose_scale_kernel(const float* __restrict__ src, int R, int Ccols,
                                                               float scale, float* __restrict__ dst) {
@@ -609,6 +629,23 @@ extern "C" int sca_theta_prep(const float* theta, int G, int C, float* tab_theta
     if (G * C <= 0) return 0;
     hipLaunchKernelGGL(theta_prep_kernel, dim3((G * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, theta, G, C,
                        tab_theta, tab_lte);
+    SCA_CHECK_LAUNCH();
+    return 0;
+}
+
+// sca_theta_prep plus two zero fills in the same launch (either may be NULL / 0 bytes; pointers 16-byte aligned, byte
+// counts multiples of 16): the per-step prologue as ONE launch.
+extern "C" int sca_theta_prep_zero(const float* theta, int G, int C, float* tab_theta, float* tab_lte, void* zero0,
+                                   long long bytes0, void* zero1, long long bytes1, void* stream) {
+    if ((((uintptr_t)zero0 | (uintptr_t)zero1) & 15) || ((bytes0 | bytes1) & 15) || bytes0 < 0 || bytes1 < 0) return -1;
+    if (!zero0) bytes0 = 0;
+    if (!zero1) bytes1 = 0;
+    const long long work = (long long)G * C > (bytes0 + bytes1) / 16 ? (long long)G * C : (bytes0 + bytes1) / 16;
+    if (work <= 0) return 0;
+    long long nb = (work + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(theta_prep_zero_kernel, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, theta, G, C,
+                       tab_theta, tab_lte, (float4*)zero0, bytes0 / 16, (float4*)zero1, bytes1 / 16);
     SCA_CHECK_LAUNCH();
     return 0;
 }

@@ -1025,7 +1025,7 @@ class CVAEEngine:
                        out=ws["pi"].data_ptr(), ldc=G, bias=P["decoder.dropout_decoder.bias"].data_ptr(),
                        force_s1=True)
         ev_side = self._flush() if self._aux_q else ev_z
-        self._wait(self._ev_pro)
+        self._wait(self._ev_tables or self._ev_pro)
         # 6. reconstruction loss (+ gradient w.r.t. the logits, in place)
         rpb = _recon_rows_per_block(B)
         gob = self.g[self.out_b].data_ptr() if self.trainable[self.out_b] else None
@@ -1066,22 +1066,40 @@ class CVAEEngine:
         xp_c = self.arch == "expimap" and self.xp_wc
 
         def work(sa):
-            if self.has_theta:
-                _lib.check(L.sca_theta_prep(P["theta"].data_ptr(), G, C, ws["tab_theta"].data_ptr(),
-                                            ws["tab_lte"].data_ptr(), sa), "theta_prep")
-                if "gam_tab" in ws:
-                    _lib.check(L.sca_nb_gamma_table(ws["tab_theta"].data_ptr(), C, G, ws["gam_tab"].data_ptr(), sa),
-                               "nb_gamma_table")
-                if compute_grad:
-                    self._zero(ws["dthetaT"], sa)
-            if compute_grad:
-                # optimizer.zero_grad(): most gradients are overwritten, the accumulating ones (output bias, column
-                # sums of large batches, embedding scatter) need zeros - one memset of the flat buffer covers all
-                self._zero(self.flat_g, sa)
+            # theta tables + dthetaT = 0 + optimizer.zero_grad() (most gradients are overwritten, the accumulating ones -
+            # output bias, column sums of large batches, embedding scatter - need zeros: one fill of the flat buffer
+            # covers all) in ONE launch where the buffers allow it
+            zt = ws["dthetaT"] if (self.has_theta and compute_grad) else None
+            zg = self.flat_g if compute_grad else None
+            nbytes = lambda t: t.numel() * t.element_size()
+            fused_ok = self.has_theta and "gam_tab" not in ws and all(
+                t is None or (t.data_ptr() % 16 == 0 and nbytes(t) % 16 == 0) for t in (zt, zg))
+            if fused_ok:
+                _lib.check(L.sca_theta_prep_zero(P["theta"].data_ptr(), G, C, ws["tab_theta"].data_ptr(),
+                                                 ws["tab_lte"].data_ptr(), _lib.ptr(zt), nbytes(zt) if zt is not None else 0,
+                                                 _lib.ptr(zg), nbytes(zg) if zg is not None else 0, sa), "theta_prep_zero")
+            else:
+                if self.has_theta:
+                    _lib.check(L.sca_theta_prep(P["theta"].data_ptr(), G, C, ws["tab_theta"].data_ptr(),
+                                                ws["tab_lte"].data_ptr(), sa), "theta_prep")
+                    if "gam_tab" in ws:
+                        _lib.check(L.sca_nb_gamma_table(ws["tab_theta"].data_ptr(), C, G, ws["gam_tab"].data_ptr(), sa),
+                                   "nb_gamma_table")
+                if zt is not None:
+                    self._zero(zt, sa)
+                if zg is not None:
+                    self._zero(zg, sa)
             if xp_c:
                 _lib.check(L.sca_transpose_scale(P[self.xp_wc].data_ptr(), self.G, self.C, 1.0,
                                                  ws["coffT"].data_ptr(), sa), "cond_transpose")
             if self._mmd_prepared:
+                if self.overlap:
+                    # what the likelihood kernel waits for ends here: the MMD's weight table below is only read by the
+                    # MMD launch, which follows it on this stream (at 128 cells the table kernel ended 12 us after the
+                    # encoder; the output GEMM / likelihood kernel waited for it for nothing)
+                    ev = self._next_event()
+                    self._call(ev.record, self.aux)
+                    self._ev_tables = (ev,)
                 # the MMD weight table only needs the conditions: built here, a whole encoder ahead of the MMD launch
                 # (a single latency-bound workgroup, ~25 us at 8192 cells, that used to sit in front of the MMD kernel)
                 bnd = -1 if self.boundary is None else int(self.boundary)
@@ -1090,6 +1108,7 @@ class CVAEEngine:
         Dm = self.Zt if (self.mmd_on == "z" or self.arch == "expimap") else self.dec[0].n_out
         self._mmd_prepared = bool(self.use_mmd and self.C > 0 and not self._dp_exact() and self._cond_cur is not None
                                   and L.sca_mmd_prepared_supported(B, Dm))
+        self._ev_tables = None
         self._defer(work)
 
     def _defer_finalize(self, recon_sign, B, accumulate_logs):
@@ -1346,7 +1365,7 @@ class CVAEEngine:
         if out_fused:
             # ONE launch: logits by MFMA into registers, softmax + likelihood + backward from there, only d-logits
             # written.  It needs the theta / gamma tables and the zeroed accumulators of the prologue.
-            self._wait(self._ev_pro)
+            self._wait(self._ev_tables or self._ev_pro)
             if after_out:
                 self._defer(mmd_work)
             ip, ix, dv = self.csr
@@ -1359,7 +1378,7 @@ class CVAEEngine:
             recon_sign = -1.0
         else:
             if after_out:
-                self._wait(self._ev_pro)
+                self._wait(self._ev_tables or self._ev_pro)
             self._gemm(0, 0, h_last, Hd, P[self.out_w].data_ptr(), Hd, B, G, Hd, st, out=ws["logits"].data_ptr(), ldc=G,
                        bias=P[self.out_b].data_ptr(), force_s1=True)
             if after_out:
@@ -1375,7 +1394,7 @@ class CVAEEngine:
             #  and the likelihood kernel - the GEMM is dispatched behind the MMD, which then holds every CU: 0.665 -> 0.753 ms;
             #  in front of the MMD's fork event, so that the MMD is not ahead of the GEMM: +4 us, twice)
             if not after_out:
-                self._wait(self._ev_pro)
+                self._wait(self._ev_tables or self._ev_pro)
             if self.recon == "mse":
                 _lib.check(L.sca_mse_rows(ws["logits"].data_ptr(), G, ws["x"].data_ptr(), G, B, G, rpb,
                                           ws["row_ll"].data_ptr(), gob, int(compute_grad), 1, None, None, st), "mse_rows")
@@ -1599,7 +1618,7 @@ class CVAEEngine:
         sf_p = ws["sf"].data_ptr()
         if lenc is not None:        # size factor = exp(sampled library latent) (expimap.py:186-187)
             sf_p = self._lenc_forward(B, cond_p, st)
-        self._wait(self._ev_pro)
+        self._wait(self._ev_tables or self._ev_pro)
         rpb = _recon_rows_per_block(B)
         if self.recon == "mse":
             _lib.check(L.sca_mse_rows(ws["logits"].data_ptr(), G, ws["x"].data_ptr(), G, B, G, rpb,
