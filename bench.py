@@ -34,6 +34,10 @@ def parse():
     ap.add_argument("--conditions", type=int, default=20)
     ap.add_argument("--hidden", type=str, default="128,128")
     ap.add_argument("--latent", type=int, default=10)
+    ap.add_argument("--pre-warm-steps", type=int, default=300,
+                    help="untimed steps BEFORE the --warmup steps (plan recording / graph capture, allocator, and the GPU's "
+                         "clock / power state: with 10 warm-up steps alone a 50-step sample reads 2 %% slower than the "
+                         "steady state - 0.578 vs 0.566 ms at 8192 cells)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-families", action="store_true",
@@ -184,16 +188,27 @@ GEMM_ENTRY_POINTS = ("sca_gemm_f32", "sca_gemm_f32_cfg", "sca_gemm_kk_f32", "sca
 VALU_PEAK_GINST = 1228.8    # 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 vector instruction (MI355X_MICROARCH.md)
 
 
-def step_plan(eng, B):
-    """The recorded launch plan of the B-cell step (the look-ahead steady-state one when there is one)."""
+def spin(fn, ms=100.0, chunk=20):
+    """Run fn back to back for ~ms milliseconds (untimed): the measurement legs below start from the GPU's steady state,
+    not from what torch's sampling kernels or an idle host phase left behind (see --pre-warm-steps)."""
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < ms:
+        for _ in range(chunk):
+            fn()
+        torch.cuda.synchronize()
+
+
+def step_plan(eng, B, rows, cond):
+    """The recorded launch plan of the B-cell step (the look-ahead steady-state one when there is one); recorded here,
+    on the real minibatch (rows, cond), when the timed run replayed a HIP graph."""
     def pick():
         plans = [(k, g["fwd"]) for k, g in getattr(eng, "_plans", {}).items() if k[0] == B and isinstance(g["fwd"], list)]
         plans.sort(key=lambda kg: kg[0][-1] != (True, True))
         return plans[0][1] if plans else None
     plan = pick()
     if plan is None:        # the timed run used a HIP graph / eager launches: record a plan of the same step once
-        eng.train_step(torch.zeros(B, dtype=torch.int64, device=eng.device),
-                       torch.zeros(B, dtype=torch.int32, device=eng.device), B, 0.5, 1e-3, use_graph="plan")
+        for _ in range(2):      # (the first call records, the second copies the minibatch into the plan's static buffers)
+            eng.train_step(rows, cond, B, 0.5, 1e-3, use_graph="plan")
         plan = pick()
     torch.cuda.synchronize()
     return plan
@@ -523,8 +538,11 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(2020 + rank)
 
-    def run(Bx, steps, warmup):
-        return run_on_stream(Bx, steps, warmup)
+    def run(Bx, steps, warmup, pre=0):
+        # `pre` untimed steps in front of the `warmup` untimed steps, all drawn in ONE sampler call up front: torch's
+        # sampling kernels (multinomial over 1M weights, argsort, gathers) right in front of a short warm-up leave the
+        # GPU 2 - 4 % below its steady state for the first tens of milliseconds (0.578 - 0.589 vs 0.566 ms per step)
+        return run_on_stream(Bx, steps, warmup + pre)
 
     def run_on_stream(Bx, steps, warmup):
         # (one minibatch more than steps: the loader runs one minibatch ahead - every timed step gathers one, the
@@ -556,7 +574,7 @@ def main():
         return dt
 
     run.in_step_loader = False
-    dt = run(B, a.steps, a.warmup)
+    dt = run(B, a.steps, a.warmup, pre=a.pre_warm_steps)
     host_issue_ms = run.host_issue_s / a.steps * 1e3
     dt_in_step = None
     if not a.no_prefetch and not a.no_loader_compare and world == 1 and not (
@@ -564,7 +582,7 @@ def main():
         # the same steps with every minibatch gathered at the head of its own step (no look-ahead): reported beside
         # the headline so that the loader's share is visible in the line itself
         run.in_step_loader = True
-        dt_in_step = run(B, a.steps, a.warmup)
+        dt_in_step = run(B, a.steps, a.warmup, pre=a.pre_warm_steps)
         run.in_step_loader = False
     value = B * world * a.steps / dt
     losses = eng.losses.tolist()
@@ -574,7 +592,7 @@ def main():
         # (all-gather of z, O(B_global^2) pair evaluations over the job) costs next to the per-rank estimator
         other = "local" if a.dp_mmd == "exact" else "exact"
         eng.set_dp(rank, world, exact_mmd=(other == "exact"))
-        dt_other = run(B, a.steps, a.warmup)
+        dt_other = run(B, a.steps, a.warmup, pre=a.pre_warm_steps)
         eng.set_dp(rank, world, exact_mmd=(a.dp_mmd == "exact"))
         extra = {f"dp_mmd_{a.dp_mmd}_ms_per_step": dt / a.steps * 1e3,
                  f"dp_mmd_{other}_ms_per_step": dt_other / a.steps * 1e3,
@@ -597,6 +615,7 @@ def main():
                           ("global minibatch (all-gather of z)" if a.dp_mmd == "exact" else "per-rank slice")},
         "final_losses": {"recon": losses[0], "kl": losses[1], "mmd": losses[2]},
         "host_issue_ms_per_step": host_issue_ms,
+        "pre_warm_steps": a.pre_warm_steps,
     }
     if dt_in_step is not None:
         out["in_step_loader"] = {"ms_per_step": dt_in_step / a.steps * 1e3, "value": B * a.steps / dt_in_step,
@@ -618,8 +637,7 @@ def main():
         flops = sum(2.0 * c[8] * c[9] * c[10] for c in single)
         flops += sum(2.0 * c[1][6] * c[1][7] * c[1][8] for c in calls if c[0] == "kk")
         st = torch.cuda.current_stream(dev)
-        for _ in range(3):
-            eng.replay_gemms(calls)
+        spin(lambda: eng.replay_gemms(calls))
         reps = 20
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(st)
@@ -663,7 +681,8 @@ def main():
         out["roofline"]["step"] = step_roofline(G, H, Z, sum(v.numel() for v in P.values()), data.numel() / n_local,
                                                 B, value / world)
         if world == 1:
-            plan = step_plan(eng, B)
+            plan = step_plan(eng, B, ids[0], cs[0])
+            spin(lambda: eng._replay(plan))
             in_step = in_step_kernel_times(eng, plan, set(GEMM_ENTRY_POINTS) | {
                 "sca_csr_gather_rows", "sca_recon_rows", "sca_recon_rows_tab", "sca_mmd_fwd_bwd_prepared",
                 "sca_mmd_fwd_bwd", "sca_mid_fwd", "sca_mid_bwd"})
@@ -680,6 +699,7 @@ def main():
             out["in_step_from"] = ("the timed run's own launch plan" if eff_launch == "plan" else
                                    "a launch plan of the same step recorded for this measurement (the timed run is "
                                    + eff_launch + "-launched: no per-launch events possible inside it)")
+            spin(lambda: eng._replay(plan))
             out["hbm_kernels"], out["valu_kernels"] = kernel_rates(eng, plan, B, G, data.numel() / n_local, in_step)
         if not a.no_sweep and world == 1:
             sweep = {}
