@@ -366,6 +366,7 @@ def family_runs(dev, steps, warmup, n_cells=200_000):
     the headline (warm-up, synchronize, K steps, synchronize), one GPU, synthetic NB counts resident in HBM as CSR:
       cfg3  expiMap, 5000 genes x 280 gene programs (hard mask, tile-skipping decoder kernels), hidden [256,256,256];
       cfg4  scPoli, 4000 genes, 200 combined conditions (40 x 5), embeddings 10 + 5, hidden [64], prototype loss on;
+      cfg2' trVAE cfg2 with the class-default hidden sizes [256, 64];
       cfg5  trVAE surgery step at HLCA shape: 2000 genes, 125 conditions, only theta + the condition columns of the two
             first layers trainable (load_query_data(freeze=True, freeze_expression=True));
       get_latent : eval-mode encoder pass (CSR gather -> encoder -> mean head) over the cfg2 matrix in 8192-cell blocks."""
@@ -458,6 +459,22 @@ def family_runs(dev, steps, warmup, n_cells=200_000):
     r["workload"] = (f"scPoli {G} genes, {Cc} combined conditions ({n_conds[0]} x {n_conds[1]}), embeddings {E}, hidden "
                      f"{H}, Z={Z}, {K} labeled prototypes (eta 5), NB; eager launches (trainers/scpoli/trainer.py path)")
     res["cfg4_scpoli_train_step"] = r
+    del eng, P, indptr, indices, data
+    torch.cuda.empty_cache()
+
+    # ---- cfg2 with the class-default hidden sizes [256, 64] (trvae_model.py:57)
+    G, C, H, Z, B = 2000, 20, [256, 64], 10, 8192
+    indptr, indices, data, cond_all, _ = make_synthetic_csr(n_cells, G, C, dev, seed=61)
+    P = build_trvae_params(G, C, H, Z, seed=6)
+    spec = dict(G=G, C=C, H=H, Z=Z, recon="nb", use_bn=False, use_ln=True, use_mmd=True, mmd_on="z", boundary=None,
+                beta=1.0, dr_rate=0.05, seed=2020)
+    eng = CVAEEngine(spec, P, dev)
+    eng.bind_csr(indptr, indices, data)
+    ids, cs = batches(cond_all, B, gen)
+    r = timed(lambda i: eng.train_step(ids[i], cs[i], B, alpha_kl=0.5, lr=1e-3, eps=0.01, weight_decay=0.04,
+                                       next_rows=ids[i + 1]), B)
+    r["workload"] = f"trVAE cfg2 with the class-default hidden sizes {H} (5.33 MFLOP / cell), {G} genes, {C} conditions, NB + MMD on z"
+    res["cfg2_class_default_256_64_train_step"] = r
     del eng, P, indptr, indices, data
     torch.cuda.empty_cache()
 

@@ -925,13 +925,11 @@ int check_and_ld(const sca_mid_args* a, int* ld, size_t* shm, int* wide) {
     return 0;
 }
 
-// SCA_MID_DIRECT: bit 0 = forward, bit 1 = backward pass through this family (A/B runs; default below)
-int direct_mask() {
-    static const int v = [] {
-        const char* e = getenv("SCA_MID_DIRECT");
-        return e ? atoi(e) : 3;
-    }();
-    return v;
+// SCA_MID_DIRECT: bit 0 = forward, bit 1 = backward pass through this family, bit 2 = generic forward kernel for
+// shapes the straight-line kernels do not take (A/B runs; default below)
+int direct_mask() {        // (read per launch: tests switch families inside one process)
+    const char* e = getenv("SCA_MID_DIRECT");
+    return e ? atoi(e) : 3;
 }
 
 }  // namespace
@@ -946,6 +944,11 @@ extern "C" int sca_midd_debug(long long* host64) {
 
 extern "C" int sca_mid_fwd(const sca_mid_args* a, void* stream) {
     if (!(direct_mask() & 1)) return sca_mid_fwd_staged(a, stream);
+    // Forward: only the straight-line 128-wide kernel beats the staged family.  The generic loop-form kernel loses its
+    // prefetch to spills and vmcnt(0) waits - [256, 64], dropout 0.05: 65 / 79 / 120 us at 128 / 4096 / 8192 cells
+    // against 48 / 46 / 88 staged (the backward one is level or ahead: 35 / 38 / 57 against 44 / 41 / 53) - so other
+    // shapes take the staged forward unless bit 2 of SCA_MID_DIRECT forces the generic kernel (tests, A/B runs).
+    if (!is_128(a) && !(direct_mask() & 4)) return sca_mid_fwd_staged(a, stream);
     int ld, wide; size_t shm;
     const int rc = check_and_ld(a, &ld, &shm, &wide);
     if (rc == 2) return sca_mid_fwd_staged(a, stream);

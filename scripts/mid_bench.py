@@ -49,7 +49,7 @@ def phases(L, rf, st, tag):
 
 RB = []
 dev = torch.device("cuda", 0)
-G, C, Z, H = 2000, 20, 10, [128, 128]
+G, C, Z, H = 2000, 20, 10, [int(x) for x in os.environ.get("MID_H", "128,128").split(",")]
 indptr, indices, data, cond_all, _ = make_synthetic_csr(50_000, G, C, dev, seed=1000)
 P = build_trvae_params(G, C, H, Z)
 gen = torch.Generator(device=dev); gen.manual_seed(1)
