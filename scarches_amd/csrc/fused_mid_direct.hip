@@ -898,6 +898,212 @@ bool is_128_bwd(const sca_mid_args* a) {
     return true;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Straight-line kernels for every other network whose hidden widths are multiples of 32 up to 256 (the class default
+// [256, 64] among them): the same written-out chain as the 128-wide kernels, with GEMMs of up to two reduction
+// super-chunks x two output blocks per wave.  Only the fragments of a wave's FIRST (block, super-chunk) item are
+// requested a phase ahead; the others are loaded where they are used (one exposed L2 round trip each).
+enum { G_FWD = 0, G_BWD = 1, G_SHORT_FWD = 2, G_SHORT_BWD = 3 };
+
+// fragments of item (jb, kc) of a GEMM in mode M:
+//   G_FWD       y = x W^T, reduction I (multiple of 16) along the rows of W: k = 128 kc + 16 i + 4 kg + u, 16-byte loads
+//   G_BWD       dx = da W, reduction I (multiple of 32) down the columns of W: k = 128 kc + 32 kg + s
+//   G_SHORT_*   the same two products for I <= 32 (z, d-heads): only lane group 0 carries data, k = s
+template <int M>
+__device__ __forceinline__ void bfrag_load_item(float (&b)[32], const float* __restrict__ W, int ldW, int I, int J, int jb,
+                                                int kc) {
+    const int lane = threadIdx.x & 63, l16 = lane & 15, kg = lane >> 4;
+    const int j = min(16 * jb + l16, J - 1);
+    if (M == G_FWD) {
+        const float* p = W + j * ldW + kc * SC + 4 * kg;
+        const int nin = (I - kc * SC) >> 4;                      // 16-wide load groups inside the row (>= 1)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 t = *reinterpret_cast<const float4*>(p + 16 * min(i, nin - 1));
+            b[4 * i] = t.x; b[4 * i + 1] = t.y; b[4 * i + 2] = t.z; b[4 * i + 3] = t.w;
+        }
+    } else if (M == G_BWD) {
+        int k0 = kc * SC + 32 * kg;
+        if (k0 + 32 > I) k0 = 0;                                  // a lane group past the reduction re-reads group 0
+        const float* p = W + k0 * ldW + j;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) b[s] = p[s * ldW];
+    } else if (M == G_SHORT_FWD) {
+        const float* p = W + j * ldW;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) b[s] = p[min(s, I - 1)];
+    } else {
+        const float* p = W + j;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) b[s] = p[min(s, I - 1) * ldW];
+    }
+}
+
+// out[r][j] = sum_i act[r][i] M(i, j) for I <= 256, J <= 256; `bf` arrives holding item (jb = wave, kc = 0).
+template <int M>
+__device__ __forceinline__ void tile_gemm_items(const float* __restrict__ act, int lda, int I, const float* __restrict__ W,
+                                                int ldW, int J, float* __restrict__ out, int ldo, float (&bf)[32]) {
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l16 = lane & 15, kg = lane >> 4;
+    const int nk = (M == G_SHORT_FWD || M == G_SHORT_BWD) ? 1 : (I + SC - 1) / SC;
+    const int lab = M == G_FWD ? 4 * kg : 32 * kg, astep = M == G_FWD ? 16 : 4;
+    __syncthreads();                                 // `act` complete
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int jb = w + NW * jj;
+        if (16 * jb < J) {
+            f32x4 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc0[r] = acc1[r] = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                if (kc < nk) {
+                    if (jj | kc) bfrag_load_item<M>(bf, W, ldW, I, J, jb, kc);
+                    const float* ap = act + l16 * lda + kc * SC + lab;
+                    float4 av[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) av[i] = *reinterpret_cast<const float4*>(ap + astep * i);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bf[4 * i], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bf[4 * i + 1], acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bf[4 * i + 2], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bf[4 * i + 3], acc1, 0, 0, 0);
+                    }
+                }
+            }
+            const int n = 16 * jb + l16;
+            if (n < J) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[(4 * kg + r) * ldo + n] = acc0[r] + acc1[r];
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <int M>
+__device__ __forceinline__ void gemm_items_prefetch(float (&bf)[32], const float* __restrict__ W, int ldW, int I, int J) {
+    bfrag_load_item<M>(bf, W, ldW, I, J, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), 0);
+}
+
+template <int NS>
+__global__ __launch_bounds__(NT, 4) void midd_fwdS_kernel(const sca_mid_args a) {
+    constexpr int ld = NS * SC + 4;
+    __shared__ __attribute__((aligned(16))) float smem[2 * TM * ld];
+    float* cur = smem;
+    float* oth = smem + TM * ld;
+    const int r0 = blockIdx.x * TM;
+    const int Z = a.Z;
+    __builtin_amdgcn_s_setprio(3);
+    warm_kernargs();
+    float wpre[32], epb[NS][4], epc[NS][4];
+    // first encoder layer: split-K slabs of its GEMM -> epilogue
+    epilogue_fwd_prefetch<NS>(a, a.first, r0, epb, epc);
+    load_tile<NS>(oth, ld, a.pre0, a.S0, a.pre0_stride, r0, a.B, a.K0, a.K0);
+    if (a.n_enc > 0) gemm_items_prefetch<G_FWD>(wpre, a.enc[0].W, a.enc[0].K, a.enc[0].K, a.enc[0].N);
+    else gemm_items_prefetch<G_FWD>(wpre, a.Wh, a.Kh, a.Kh, 2 * Z);
+    __syncthreads();
+    layer_epilogue_fwd<NS>(a, a.first, oth, cur, ld, r0, epb, epc);
+    for (int l = 0; l < a.n_enc; ++l) {
+        const sca_mid_layer& L = a.enc[l];
+        epilogue_fwd_prefetch<NS>(a, L, r0, epb, epc);
+        tile_gemm_items<G_FWD>(cur, ld, L.K, L.W, L.K, L.N, oth, ld, wpre);
+        if (l + 1 < a.n_enc) gemm_items_prefetch<G_FWD>(wpre, a.enc[l + 1].W, a.enc[l + 1].K, a.enc[l + 1].K, a.enc[l + 1].N);
+        else gemm_items_prefetch<G_FWD>(wpre, a.Wh, a.Kh, a.Kh, 2 * Z);
+        layer_epilogue_fwd<NS>(a, L, oth, cur, ld, r0, epb, epc);
+    }
+    // heads -> sample + KL
+    tile_gemm_items<G_FWD>(cur, ld, a.Kh, a.Wh, a.Kh, 2 * Z, oth, ld, wpre);
+    gemm_items_prefetch<G_SHORT_FWD>(wpre, a.dec[0].W, Z, Z, a.dec[0].N);
+    epilogue_fwd_prefetch<NS>(a, a.dec[0], r0, epb, epc);
+    latent_fwd_block(a, oth, cur, ld, r0);
+    // decoder: z -> first layer (short reduction), then the hidden layers
+    tile_gemm_items<G_SHORT_FWD>(cur, ld, Z, a.dec[0].W, Z, a.dec[0].N, oth, ld, wpre);
+    if (a.n_dec > 1) gemm_items_prefetch<G_FWD>(wpre, a.dec[1].W, a.dec[1].K, a.dec[1].K, a.dec[1].N);
+    layer_epilogue_fwd<NS>(a, a.dec[0], oth, cur, ld, r0, epb, epc);
+    for (int l = 1; l < a.n_dec; ++l) {
+        const sca_mid_layer& L = a.dec[l];
+        epilogue_fwd_prefetch<NS>(a, L, r0, epb, epc);
+        tile_gemm_items<G_FWD>(cur, ld, L.K, L.W, L.K, L.N, oth, ld, wpre);
+        if (l + 1 < a.n_dec) gemm_items_prefetch<G_FWD>(wpre, a.dec[l + 1].W, a.dec[l + 1].K, a.dec[l + 1].K, a.dec[l + 1].N);
+        layer_epilogue_fwd<NS>(a, L, oth, cur, ld, r0, epb, epc);
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(NT, 4) void midd_bwdS_kernel(const sca_mid_args a) {
+    constexpr int ld = NS * SC + 4;
+    __shared__ __attribute__((aligned(16))) float smem[2 * TM * ld];
+    float* cur = smem;
+    float* oth = smem + TM * ld;
+    const int r0 = blockIdx.x * TM;
+    const int Z = a.Z;
+    __builtin_amdgcn_s_setprio(3);
+    warm_kernargs();
+    float wpre[32], ypre[NS][4], rspre = 0.f;
+    {
+        const sca_mid_layer& L = a.dec[a.n_dec - 1];
+        epilogue_bwd_prefetch<NS>(a, L, false, r0, ypre, rspre);
+        load_tile<NS>(cur, ld, a.dh, a.S, a.dh_stride, r0, a.B, L.N, L.N);
+        gemm_items_prefetch<G_BWD>(wpre, L.W, L.K, L.N, L.K);     // dX = da W: L.N outputs reduced, L.K inputs
+    }
+    __syncthreads();
+    for (int l = a.n_dec - 1; l >= 0; --l) {
+        const sca_mid_layer& L = a.dec[l];
+        layer_epilogue_bwd<NS>(a, L, cur, oth, ld, r0, ypre, rspre);           // oth = da [TM][L.N]
+        if (l > 0) epilogue_bwd_prefetch<NS>(a, a.dec[l - 1], false, r0, ypre, rspre);
+        tile_gemm_items<G_BWD>(oth, ld, L.N, L.W, L.K, L.K, cur, ld, wpre);    // cur = dX [TM][L.K]
+        if (l > 0) gemm_items_prefetch<G_BWD>(wpre, a.dec[l - 1].W, a.dec[l - 1].K, a.dec[l - 1].N, a.dec[l - 1].K);
+        else gemm_items_prefetch<G_SHORT_BWD>(wpre, a.Wh, a.Kh, 2 * Z, a.Kh);
+    }
+    latent_bwd_block(a, cur, oth, ld, r0);                                     // oth = d[mean | log_var], zero padded
+    if (a.n_enc > 0) epilogue_bwd_prefetch<NS>(a, a.enc[a.n_enc - 1], false, r0, ypre, rspre);
+    else epilogue_bwd_prefetch<NS>(a, a.first, false, r0, ypre, rspre);
+    tile_gemm_items<G_SHORT_BWD>(oth, ld, 2 * Z, a.Wh, a.Kh, a.Kh, cur, ld, wpre);      // heads backward
+    if (a.n_enc > 0) {
+        const sca_mid_layer& L = a.enc[a.n_enc - 1];
+        gemm_items_prefetch<G_BWD>(wpre, L.W, L.K, L.N, L.K);
+    }
+    for (int l = a.n_enc - 1; l >= 0; --l) {
+        const sca_mid_layer& L = a.enc[l];
+        layer_epilogue_bwd<NS>(a, L, cur, oth, ld, r0, ypre, rspre);
+        if (l > 0) epilogue_bwd_prefetch<NS>(a, a.enc[l - 1], false, r0, ypre, rspre);
+        else epilogue_bwd_prefetch<NS>(a, a.first, false, r0, ypre, rspre);
+        tile_gemm_items<G_BWD>(oth, ld, L.N, L.W, L.K, L.K, cur, ld, wpre);
+        if (l > 0) gemm_items_prefetch<G_BWD>(wpre, a.enc[l - 1].W, a.enc[l - 1].K, a.enc[l - 1].N, a.enc[l - 1].K);
+    }
+    layer_epilogue_bwd<NS>(a, a.first, cur, oth, ld, r0, ypre, rspre);         // da of the first layer feeds its dW GEMM
+}
+
+// shapes the generalised straight-line kernels take: every width a multiple of 32 up to 256, fused first layer, Z <= 16
+bool is_S(const sca_mid_args* a, bool bwd, int* wide) {
+    auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
+    auto okw = [](int n) { return n >= 32 && n <= MAXW && (n & 31) == 0; };
+    if (a->n_enc < 0 || a->n_enc > 4 || a->n_dec < 1 || a->n_dec > 4 || a->S0 < 1) return false;
+    if (!a->fuse_first || !okw(a->K0) || !okw(a->Kh) || a->Z < 1 || a->Z > 16 || !a->pre0) return false;
+    if (a->first.N != a->K0 || (a->pre0_stride & 3) || !al(a->pre0) || !al(a->Wh) || !al(a->first.yn) || !al(a->first.h))
+        return false;
+    int maxn = a->K0, prev = a->K0;
+    for (int l = 0; l < a->n_enc; ++l) {
+        const sca_mid_layer& L = a->enc[l];
+        if (!okw(L.N) || L.K != prev || !al(L.W) || !al(L.yn) || !al(L.h) || (bwd && !al(L.da))) return false;
+        prev = L.N;
+        if (L.N > maxn) maxn = L.N;
+    }
+    if (a->Kh != prev) return false;
+    prev = a->Z;
+    for (int l = 0; l < a->n_dec; ++l) {
+        const sca_mid_layer& L = a->dec[l];
+        if (!okw(L.N) || L.K != prev || !al(L.W) || !al(L.yn) || !al(L.h) || (bwd && !al(L.da))) return false;
+        prev = L.N;
+        if (L.N > maxn) maxn = L.N;
+    }
+    if (bwd && (!a->dh || (a->dh_stride & 3) || !al(a->dh) || !al(a->first.da))) return false;
+    *wide = maxn > SC;
+    return true;
+}
+
 int check_and_ld(const sca_mid_args* a, int* ld, size_t* shm, int* wide) {
     if (a->B <= 0) return 1;
     if (a->n_enc < 0 || a->n_enc > 4 || a->n_dec < 0 || a->n_dec > 4) return -1;
@@ -925,8 +1131,8 @@ int check_and_ld(const sca_mid_args* a, int* ld, size_t* shm, int* wide) {
     return 0;
 }
 
-// SCA_MID_DIRECT: bit 0 = forward, bit 1 = backward pass through this family, bit 2 = generic forward kernel for
-// shapes the straight-line kernels do not take (A/B runs; default below)
+// SCA_MID_DIRECT: bit 0 = forward, bit 1 = backward pass through this family, bit 2 = the generic loop-form kernels for
+// every shape but the 128-wide one, bit 3 = no generalised straight-line kernels (A/B runs; default below)
 int direct_mask() {        // (read per launch: tests switch families inside one process)
     const char* e = getenv("SCA_MID_DIRECT");
     return e ? atoi(e) : 3;
@@ -948,6 +1154,17 @@ extern "C" int sca_mid_fwd(const sca_mid_args* a, void* stream) {
     // prefetch to spills and vmcnt(0) waits - [256, 64], dropout 0.05: 65 / 79 / 120 us at 128 / 4096 / 8192 cells
     // against 48 / 46 / 88 staged (the backward one is level or ahead: 35 / 38 / 57 against 44 / 41 / 53) - so other
     // shapes take the staged forward unless bit 2 of SCA_MID_DIRECT forces the generic kernel (tests, A/B runs).
+    {
+        int wideS;
+        if (!is_128(a) && !(direct_mask() & 4) && is_S(a, false, &wideS) && !(direct_mask() & 8)) {
+            if (a->B <= 0) return 0;
+            const dim3 gridS((a->B + TM - 1) / TM);
+            if (wideS) hipLaunchKernelGGL(midd_fwdS_kernel<2>, gridS, dim3(NT), 0, (hipStream_t)stream, *a);
+            else hipLaunchKernelGGL(midd_fwdS_kernel<1>, gridS, dim3(NT), 0, (hipStream_t)stream, *a);
+            SCA_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     if (!is_128(a) && !(direct_mask() & 4)) return sca_mid_fwd_staged(a, stream);
     int ld, wide; size_t shm;
     const int rc = check_and_ld(a, &ld, &shm, &wide);
@@ -973,6 +1190,13 @@ extern "C" int sca_mid_bwd(const sca_mid_args* a, void* stream) {
     if (rc) return rc > 0 ? 0 : rc;
     if (!a->dh || !a->dheads || !a->hyper || (!a->fuse_first && !a->dh_out)) return -1;
     const dim3 grid((a->B + TM - 1) / TM);
+    int wideS;
+    if (!is_128_bwd(a) && !(direct_mask() & 4) && !(direct_mask() & 8) && is_S(a, true, &wideS)) {
+        if (wideS) hipLaunchKernelGGL(midd_bwdS_kernel<2>, grid, dim3(NT), 0, (hipStream_t)stream, *a);
+        else hipLaunchKernelGGL(midd_bwdS_kernel<1>, grid, dim3(NT), 0, (hipStream_t)stream, *a);
+        SCA_CHECK_LAUNCH();
+        return 0;
+    }
     if (is_128_bwd(a)) {
         hipLaunchKernelGGL(midd_bwd128_kernel, grid, dim3(NT), 0, (hipStream_t)stream, *a);
     } else if (wide) {

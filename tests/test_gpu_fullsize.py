@@ -344,15 +344,16 @@ def test_recorded_plans_survive_a_workspace_regrowth(data, mode):
     assert d <= 1e-5 * float(b.flat_p.abs().max()), d
 
 
-@pytest.mark.parametrize("Hx,Zx,Bx", [([128, 128], 10, 1000), ([128, 128, 128], 16, 77), ([256, 64], 10, 515),
-                                      ([64], 5, 130)])
-def test_mid_direct_family_matches_staged_family(Hx, Zx, Bx, monkeypatch):
+@pytest.mark.parametrize("Hx,Zx,Bx,mask", [([128, 128], 10, 1000, "3"), ([128, 128, 128], 16, 77, "3"),
+                                           ([256, 64], 10, 515, "7"), ([256, 64], 10, 515, "3"), ([64], 5, 130, "3"),
+                                           ([96, 32, 160], 7, 300, "3"), ([96, 32, 160], 7, 300, "7")])
+def test_mid_direct_family_matches_staged_family(Hx, Zx, Bx, mask, monkeypatch):
     """sca_mid_fwd / sca_mid_bwd (fragments straight from L2: the straight-line 128-wide kernels, the generic direct
     kernels) against sca_mid_fwd_staged / sca_mid_bwd_staged (weights through LDS) on the SAME argument block: every
-    tensor either pass writes agrees to rounding (the two families sum in different orders).  SCA_MID_DIRECT=7 also
-    sends shapes other than 128-wide through the generic direct FORWARD kernel, which the default routes to the staged
-    family (it is slower there)."""
-    monkeypatch.setenv("SCA_MID_DIRECT", "7")
+    tensor either pass writes agrees to rounding (the two families sum in different orders).  SCA_MID_DIRECT=3 (the
+    default) takes the straight-line kernels - 128-wide, or the generalised ones for widths that are multiples of 32 -
+    and 7 forces the generic loop-form kernels for every shape but the 128-wide one."""
+    monkeypatch.setenv("SCA_MID_DIRECT", mask)
     from bench import build_trvae_params
     from scarches_amd import _lib
     from scarches_amd.engine import CVAEEngine
