@@ -594,8 +594,10 @@ def main():
     dt = run(B, a.steps, a.warmup, pre=a.pre_warm_steps)
     host_issue_ms = run.host_issue_s / a.steps * 1e3
     dt_in_step = None
-    if not a.no_prefetch and not a.no_loader_compare and world == 1 and not (
-            a.launch == "graph" or (a.launch == "auto" and B <= __import__("scarches_amd.engine", fromlist=["GRAPH_MAX_B"]).GRAPH_MAX_B)):
+    from scarches_amd.engine import GRAPH_MAX_B
+    eff_launch = ({"plan": "plan", "graph": "graph", "eager": "eager"}.get(a.launch)
+                  or ("graph" if (B <= GRAPH_MAX_B and world == 1) else "plan"))
+    if not a.no_prefetch and not a.no_loader_compare and world == 1 and eff_launch == "plan":
         # the same steps with every minibatch gathered at the head of its own step (no look-ahead): reported beside
         # the headline so that the loader's share is visible in the line itself
         run.in_step_loader = True
@@ -615,9 +617,6 @@ def main():
                  f"dp_mmd_{other}_ms_per_step": dt_other / a.steps * 1e3,
                  f"dp_mmd_{other}_cells_per_s": B * world * a.steps / dt_other}
 
-    from scarches_amd.engine import GRAPH_MAX_B
-    eff_launch = ({"plan": "plan", "graph": "graph", "eager": "eager"}.get(a.launch)
-                  or ("graph" if (B <= GRAPH_MAX_B and world == 1) else "plan"))
     out = {
         "metric": "train cells/sec (fwd+bwd+Adam) trVAE 2k-HVG", "value": value, "unit": "cells/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,

@@ -392,10 +392,6 @@ __device__ __forceinline__ void warm_kernargs() {
     asm volatile("" ::"s"(acc));
 }
 
-__device__ __forceinline__ bool fwd_vec(const float* W, int I) {
-    return (I & 15) == 0 && (((uintptr_t)W) & 15) == 0;    // (forward: ldW == I)
-}
-
 // heads (tile `oth`: [mean | log_var] pre-bias) -> reparameterised sample + KL; z tile -> `cur`, zero padded
 __device__ __forceinline__ void latent_fwd_block(const sca_mid_args& a, float* __restrict__ oth, float* __restrict__ cur,
                                                  int ld, int r0) {
@@ -480,7 +476,6 @@ __global__ __launch_bounds__(NT, 4) void midd_fwd_kernel(const sca_mid_args a, i
     const int r0 = blockIdx.x * TM;
     float* cur = A0;
     float* oth = A1;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     __builtin_amdgcn_s_setprio(3);     // latency-bound chain on the step's critical path (see fused_mid.hip)
     warm_kernargs();
     DBG(15);
@@ -636,7 +631,6 @@ __global__ __launch_bounds__(NT, 4) void midd_bwd_kernel(const sca_mid_args a, i
     float* A1 = A0 + TM * ld;
     const int r0 = blockIdx.x * TM;
     const int Z = a.Z;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     __builtin_amdgcn_s_setprio(3);
     warm_kernargs();
     DBG(32);
