@@ -104,7 +104,11 @@ class CVAEEngine:
         self._adam_done = False
         self._dp_split = False          # True while a data-parallel step is issued: all-reduce between tail and Adam
         self._dp_world, self._dp_grad_weight = 1, None
-        self._mid_max_split = None      # optional split-K cap of the two GEMMs whose slabs the fused kernels sum
+        # split-K cap of the two GEMMs whose slabs the fused middle kernels sum tile by tile: the planner's 32 slabs at
+        # <= 1024 cells cost the 16-cell tiles more (four rounds of slab loads) than the GEMMs gain - cfg2 step, graph
+        # launched: 128 cells 0.1446 - 0.1485 ms with 32, 0.1413 with 16, 0.1445 with 8, 0.161 with 4; 1024 cells 0.1954 /
+        # 0.188 / 0.190 / 0.207 (SCA_MID_MAX_SPLIT overrides)
+        self._mid_max_split = int(os.environ.get("SCA_MID_MAX_SPLIT") or 16)
         self.lib = _RecordingLib(_lib.load(), self)
         self.device = torch.device(device)
         if self.device.type != "cuda":
