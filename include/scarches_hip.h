@@ -281,7 +281,9 @@ int sca_grad_tail(const sca_tail_job* jobs, int n_jobs, void* stream);
  * the first encoder layer) and writes every tensor the unfused kernels write (yn, rs, h per layer, mu_lv, eps, z,
  * kl_row); sca_mid_bwd consumes the dX slabs of the output GEMM (dh, S, dh_stride) and optional dz2 [B][Z], writes the
  * per-layer da, dheads and dh_out [B][K0] (gradient w.r.t. h_in).  Layer widths <= sca_mid_max_width().  `a` is a HOST
- * struct (copied into the kernel arguments). */
+ * struct (copied into the kernel arguments).  Encoder-only forward pass (get_latent, _base.py:285-340): n_dec = 0 with
+ * dec[0] still naming the first decoder layer's weights (the kernels prefetch them before they return), and
+ * yn = rs = h = NULL in every layer = nothing is kept for a backward pass. */
 typedef struct {
     const float* W; const float* bias; const float* Wc; const uint8_t* mask;
     float* yn; float* rs; float* h; float* da;

@@ -314,7 +314,7 @@ __device__ __forceinline__ void layer_epilogue_fwd(const sca_mid_args& a, const 
                 }
         rs = 1.0f / sqrtf(row_sum(sq) / (float)N + 1e-5f);
     }
-    if (t8 == 0 && live) L.rs[b] = rs;
+    if (t8 == 0 && live && L.rs) L.rs[b] = rs;
     const float keep_scale = a.p > 0.f ? 1.0f / (1.0f - a.p) : 1.f;
     const uint32_t stp = a.step ? a.step[0] : 0u;
     float* nrow = nxt + row * ld;
@@ -340,7 +340,7 @@ __device__ __forceinline__ void layer_epilogue_fwd(const sca_mid_args& a, const 
             }
             nrow[hh] = ov[u];
         }
-        if (live) {
+        if (live && L.yn) {             // (eval-mode encoder passes keep nothing: yn == h == NULL)
             const long long g = (long long)b * N + h4;
             if (vec) {
                 if (h4 < N) {

@@ -339,7 +339,7 @@ __device__ __forceinline__ void layer_epilogue_fwd(const sca_mid_args& a, const 
                 }
         rs = 1.0f / sqrtf(row_sum(sq) / (float)N + 1e-5f);
     }
-    if (tr == 0 && live) L.rs[b] = rs;
+    if (tr == 0 && live && L.rs) L.rs[b] = rs;
     const float keep_scale = a.p > 0.f ? 1.0f / (1.0f - a.p) : 1.f;
     const uint32_t stp = a.step ? a.step[0] : 0u;
     float* nrow = nxt + row * ld;
@@ -365,7 +365,7 @@ __device__ __forceinline__ void layer_epilogue_fwd(const sca_mid_args& a, const 
             }
         }
         *reinterpret_cast<float4*>(nrow + h4) = make_float4(ov[0], ov[1], ov[2], ov[3]);
-        if (live) {
+        if (live && L.yn) {             // (eval-mode encoder passes keep nothing: yn == h == NULL)
             const long long g = (long long)b * N + h4;
             if (vec) {
                 if (h4 < N) {
@@ -795,6 +795,7 @@ __global__ __launch_bounds__(NT, 4) void midd_fwd128_kernel(const sca_mid_args a
     DBG(mark++);
     latent_fwd_block(a, oth, cur, ld, r0);
     DBG(mark++);
+    if (a.n_dec == 0) return;          // encoder only (get_latent); dec[0] still names valid operands for the prefetch above
     // decoder: z -> first layer (short reduction, labelling k = 32 kg + s), then 128 x 128 layers
     tile_gemm_full<false>(cur, ld, SC, oth, ld, wpre);
     if (a.n_dec > 1) bfrag_load_full<true>(wpre, a.dec[1].W, SC, SC);
@@ -870,7 +871,9 @@ __global__ __launch_bounds__(NT, 4) void midd_bwd128_kernel(const sca_mid_args a
 // shapes the straight-line kernels take
 bool is_128(const sca_mid_args* a) {
     auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
-    if (!a->fuse_first || a->K0 != SC || a->Kh != SC || a->Z < 1 || a->Z > 16 || a->n_dec < 1 || !a->pre0) return false;
+    if (!a->fuse_first || a->K0 != SC || a->Kh != SC || a->Z < 1 || a->Z > 16 || a->n_dec < 0 || !a->pre0) return false;
+    // (n_dec == 0 = encoder only: the kernel still prefetches the first decoder layer's operands)
+    if (a->n_dec == 0 && (!a->dec[0].W || !al(a->dec[0].W) || a->dec[0].N != SC || a->dec[0].K != a->Z)) return false;
     if (a->first.N != SC || (a->pre0_stride & 3) || !al(a->pre0) || !al(a->Wh)) return false;
     if (!al(a->first.yn) || !al(a->first.h)) return false;
     for (int l = 0; l < a->n_enc; ++l) {
@@ -886,7 +889,7 @@ bool is_128(const sca_mid_args* a) {
 
 bool is_128_bwd(const sca_mid_args* a) {
     auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
-    if (!is_128(a) || !a->dh || (a->dh_stride & 3) || !al(a->dh) || !al(a->first.da)) return false;
+    if (!is_128(a) || a->n_dec < 1 || !a->dh || (a->dh_stride & 3) || !al(a->dh) || !al(a->first.da)) return false;
     for (int l = 0; l < a->n_enc; ++l) if (!al(a->enc[l].da)) return false;
     for (int l = 0; l < a->n_dec; ++l) if (!al(a->dec[l].da)) return false;
     return true;
@@ -1012,6 +1015,7 @@ __global__ __launch_bounds__(NT, 4) void midd_fwdS_kernel(const sca_mid_args a) 
     gemm_items_prefetch<G_SHORT_FWD>(wpre, a.dec[0].W, Z, Z, a.dec[0].N);
     epilogue_fwd_prefetch<NS>(a, a.dec[0], r0, epb, epc);
     latent_fwd_block(a, oth, cur, ld, r0);
+    if (a.n_dec == 0) return;          // encoder only (get_latent); dec[0] still names valid operands for the prefetch above
     // decoder: z -> first layer (short reduction), then the hidden layers
     tile_gemm_items<G_SHORT_FWD>(cur, ld, Z, a.dec[0].W, Z, a.dec[0].N, oth, ld, wpre);
     if (a.n_dec > 1) gemm_items_prefetch<G_FWD>(wpre, a.dec[1].W, a.dec[1].K, a.dec[1].K, a.dec[1].N);
@@ -1074,7 +1078,9 @@ __global__ __launch_bounds__(NT, 4) void midd_bwdS_kernel(const sca_mid_args a) 
 bool is_S(const sca_mid_args* a, bool bwd, int* wide) {
     auto al = [](const void* p) { return (((uintptr_t)p) & 15) == 0; };
     auto okw = [](int n) { return n >= 32 && n <= MAXW && (n & 31) == 0; };
-    if (a->n_enc < 0 || a->n_enc > 4 || a->n_dec < 1 || a->n_dec > 4 || a->S0 < 1) return false;
+    if (a->n_enc < 0 || a->n_enc > 4 || a->n_dec < 0 || a->n_dec > 4 || a->S0 < 1) return false;
+    // (n_dec == 0 = encoder only, forward pass: the kernel still prefetches the first decoder layer's operands)
+    if (a->n_dec == 0 && (bwd || !a->dec[0].W || !al(a->dec[0].W) || !okw(a->dec[0].N) || a->dec[0].K != a->Z)) return false;
     if (!a->fuse_first || !okw(a->K0) || !okw(a->Kh) || a->Z < 1 || a->Z > 16 || !a->pre0) return false;
     if (a->first.N != a->K0 || (a->pre0_stride & 3) || !al(a->pre0) || !al(a->Wh) || !al(a->first.yn) || !al(a->first.h))
         return false;

@@ -1268,11 +1268,14 @@ class CVAEEngine:
         self._wait(self._flush())
 
     # ------------------------------------------------------------------------------------------ fused middle
-    def _mid_args(self, B, cond_p, p_drop, eps, masks, dh=None, S=0, stride=0, dz2=None, pre0=None):
-        """sca_mid_args for the current workspace (cached: every pointer is static for a given batch capacity)."""
+    def _mid_args(self, B, cond_p, p_drop, eps, masks, dh=None, S=0, stride=0, dz2=None, pre0=None, sample=1,
+                  encoder_only=False):
+        """sca_mid_args for the current workspace (cached: every pointer is static for a given batch capacity).
+        encoder_only: n_dec = 0 - the forward kernel stops behind the latent block (get_latent); the decoder entries
+        stay filled, the straight-line kernels prefetch the first decoder layer's operands before they return."""
         P, ws, ptr = self.p, self.ws, _lib.ptr
         key = (B, self._ws_gen, self.seed, cond_p, p_drop, ptr(eps), tuple(sorted((k, v.data_ptr()) for k, v in masks.items())), dh, S,
-               stride, dz2, pre0)
+               stride, dz2, pre0, sample, encoder_only)
         cache = self.__dict__.setdefault("_mid_cache", {})
         hit = cache.get(key)
         if hit is not None:
@@ -1287,16 +1290,18 @@ class CVAEEngine:
             dst.mask = ptr(masks.get(ly.mask_key))
             dst.yn, dst.rs = ws[ly.tag + ".yn"].data_ptr(), ws[ly.tag + ".rs"].data_ptr()
             dst.h, dst.da = ws[ly.tag + ".h"].data_ptr(), ws[ly.tag + ".da"].data_ptr()
+            if encoder_only:        # eval-mode encoder pass: nothing is kept for a backward pass
+                dst.yn = dst.rs = dst.h = None
             dst.N, dst.K, dst.rng_stream = ly.n_out, ly.n_in, ly.rng_stream
         for i, ly in enumerate(self.enc[1:]):
             fill(a.enc[i], ly)
         for i, ly in enumerate(self.dec):
             fill(a.dec[i], ly)
-        a.n_enc, a.n_dec = len(self.enc) - 1, len(self.dec)
+        a.n_enc, a.n_dec = len(self.enc) - 1, 0 if encoder_only else len(self.dec)
         a.Wh, a.bh, a.eps_in = self.heads_w.data_ptr(), self.heads_b.data_ptr(), ptr(eps)
         a.mu_lv, a.eps_out = ws["mu_lv"].data_ptr(), ws["eps"].data_ptr()
         a.z, a.kl_row = ws["z"].data_ptr(), ws["kl_row"].data_ptr()
-        a.Z, a.Kh, a.rng_latent, a.sample = self.Zt, self.H[-1], 1, 1
+        a.Z, a.Kh, a.rng_latent, a.sample = self.Zt, self.H[-1], 1, int(sample)
         a.B, a.C, a.cond = B, self.C, cond_p
         a.norm, a.p, a.seed, a.step = self.norm, p_drop, self.seed, self.step_ctr.data_ptr()
         a.h_in, a.K0, a.S = ws[self.enc[0].tag + ".h"].data_ptr(), self.H[0], S
@@ -2162,6 +2167,18 @@ class CVAEEngine:
                                              ws["x"].data_ptr(), G, ws["sf"].data_ptr(), st), "csr_gather")
         a = ws["x"].data_ptr()
         cond_p = ptr(cond) if C > 0 else None
+        if self.use_fused_mid and not self.cond_embed and os.environ.get("SCA_ENCODE_FUSED", "1") == "1":
+            # first-layer GEMM, then ONE launch for its epilogue, the remaining encoder layers, the heads and the latent
+            # block (sca_mid_fwd with n_dec = 0) instead of a GEMM + epilogue pair per layer
+            ly = self.enc[0]
+            pre0 = self._gemm(0, 0, a, ly.n_in, P[ly.w].data_ptr(), ly.n_in, B, ly.n_out, ly.n_in, st,
+                              max_split=self._mid_max_split)
+            self.step_ctr += 1          # fresh noise for every sampled pass
+            _lib.check(L.sca_mid_fwd(self._mid_args(B, cond_p, 0.0, eps, {}, pre0=pre0, sample=0 if mean else 1,
+                                                    encoder_only=True), st), "mid_fwd[encode]")
+            mu = ws["mu_lv"][:B, :Z]
+            var = torch.exp(ws["mu_lv"][:B, Z:]) + 1e-4
+            return ws["z"][:B], mu, var
         if self.cond_embed:
             self._embed_lookup(covs, B, st)
             cw, cwp, cvec_p, cE = 0, None, ws["cvec"].data_ptr(), self.E

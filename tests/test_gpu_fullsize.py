@@ -420,3 +420,37 @@ def test_captured_step_with_side_streams_waiting_for_each_other(data, monkeypatc
     (la, pa), (lb, pb) = outs
     assert np.all(np.abs(la[:3] - lb[:3]) <= 1e-5 * np.abs(lb[:3])), (la, lb)
     assert float((pa - pb).abs().max()) <= 1e-5 * float(pb.abs().max())
+
+
+@pytest.mark.parametrize("Hx,Zx,Bx", [([128, 128], 10, 1000), ([256, 64], 10, 515), ([100, 37], 7, 77), ([64], 5, 130)])
+@pytest.mark.parametrize("mean", [True, False])
+def test_encode_fused_matches_per_layer_encode(Hx, Zx, Bx, mean, monkeypatch):
+    """get_latent's encoder pass: first-layer GEMM + ONE sca_mid_fwd launch with n_dec = 0 (straight-line 128-wide,
+    generalised, staged kernels by shape) against the GEMM + epilogue pair per layer, eval mode, mean and sampled z
+    (injected noise)."""
+    from bench import build_trvae_params
+    from scarches_amd.engine import CVAEEngine
+    from scarches_amd.synth import make_synthetic_csr
+    Gx, Cx = 300, 3
+    dev = torch.device("cuda", 0)
+    indptr, indices, vals, cond_all, _ = make_synthetic_csr(3000, Gx, Cx, dev, seed=5)
+    rows = torch.arange(Bx, device=dev)
+    cond = cond_all[rows].to(torch.int32).contiguous()
+    eps = torch.randn(Bx, Zx, device=dev, generator=torch.Generator(device=dev).manual_seed(2))
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SCA_ENCODE_FUSED", flag)
+        spec = dict(G=Gx, C=Cx, H=Hx, Z=Zx, recon="nb", use_bn=False, use_ln=True, use_mmd=True, mmd_on="z",
+                    boundary=None, beta=1.0, dr_rate=0.1, seed=11)
+        e = CVAEEngine(spec, build_trvae_params(Gx, Cx, Hx, Zx), dev)
+        e.bind_csr(indptr, indices, vals)
+        z, mu, var = e.encode(rows, cond, Bx, mean=mean, eps=eps)
+        torch.cuda.synchronize()
+        outs.append((z.clone(), mu.clone(), var.clone()))
+    for a, b in zip(*outs):
+        assert torch.isfinite(b).all()
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-7
+    if mean:
+        assert torch.equal(outs[0][0], outs[0][1])          # z is the mean
+    else:
+        assert float((outs[0][0] - outs[0][1]).abs().max()) > 1e-3
