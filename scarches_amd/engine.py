@@ -83,9 +83,18 @@ def _recon_rows_per_block(B):
     """Rows a likelihood workgroup walks (theta gradients stay in registers across them): ~512 workgroups = two per
     CU, at most 16 rows.  Measured inside the cfg2 step (scripts/ab_env.sh, ms/step): B=1024 0.305 / 0.287 / 0.293 with
     1 / 2 / 4 rows, B=2048 0.326 / 0.313 / 0.335 with 2 / 4 / 8, B=4096 0.431 / 0.409 / 0.396 / 0.444 with 2 / 4 / 8 / 16,
-    B=8192 0.695 / 0.693 / 0.673 / 0.674 with 2 / 4 / 8 / 16.  SCA_RECON_RPB overrides it for A/B runs."""
+    B=8192 0.695 / 0.693 / 0.673 / 0.674 with 2 / 4 / 8 / 16.  SCA_RECON_RPB overrides it for A/B runs.
+    Round 3, the step replayed as a HIP graph (MMD forked behind the output GEMM, the likelihood kernel placed first):
+    8192 cells 0.603 / 0.563 / 0.565 / 0.552 / 0.552 / 0.559 / 0.601 ms with 8 / 16 / 18 / 20 / 22 / 24 / 32 rows (three
+    runs each for 16 and 20) - 20 rows there; 7168 cells 0.493 / 0.492 / 0.495 with 14 / 16 / 18, 6144: 0.422 / 0.428 with
+    12 / 15, 4096: 8 - 9 rows, so the rule below stays elsewhere; launch plans at 8192 cells want 16 (0.574 vs 0.601
+    with 20): the MMD is forked ahead of the likelihood kernel there."""
     v = os.environ.get("SCA_RECON_RPB")
-    return max(1, int(v)) if v else min(16, max(1, B // 512))
+    if v:
+        return max(1, int(v))
+    if B > 7680 and B <= GRAPH_MAX_B and torch.cuda.is_current_stream_capturing():
+        return 20
+    return min(16, max(1, B // 512))
 
 
 class CVAEEngine:
