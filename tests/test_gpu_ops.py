@@ -534,3 +534,33 @@ def test_latent_fwd_narrow_and_wide_rows(Z):
     assert torch.equal(eo, eps)
     assert float((z.double() - z_ref).abs().max()) <= 1e-5
     assert float(((kl.double() - kl_ref).abs() / kl_ref.abs().clamp_min(1e-3)).max()) <= 1e-5
+
+
+def test_theta_prep_zero_matches_theta_prep_and_fills():
+    """sca_theta_prep_zero = sca_theta_prep + two zero fills in one launch: identical tables, both ranges zeroed and
+    nothing beyond them touched; NULL ranges, G * C == 0 and misaligned ranges (-1)."""
+    from scarches_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    G, C = 333, 7
+    theta = torch.randn(G, C, device="cuda")
+    t0, l0 = torch.empty(C, G, device="cuda"), torch.empty(C, G, device="cuda")
+    t1, l1 = torch.full((C, G), float("nan"), device="cuda"), torch.full((C, G), float("nan"), device="cuda")
+    _lib.check(lib.sca_theta_prep(theta.data_ptr(), G, C, t0.data_ptr(), l0.data_ptr(), st), "theta_prep")
+    za = torch.full((4 * 1000 + 8,), 3.0, device="cuda")
+    zb = torch.full((4 * 70001 + 8,), 5.0, device="cuda")
+    _lib.check(lib.sca_theta_prep_zero(theta.data_ptr(), G, C, t1.data_ptr(), l1.data_ptr(), za.data_ptr(), 16 * 1000,
+                                       zb.data_ptr(), 16 * 70001, st), "theta_prep_zero")
+    torch.cuda.synchronize()
+    assert torch.equal(t0, t1) and torch.equal(l0, l1)
+    assert float(za[:4000].abs().max()) == 0.0 and torch.all(za[4000:] == 3.0)
+    assert float(zb[:4 * 70001].abs().max()) == 0.0 and torch.all(zb[4 * 70001:] == 5.0)
+    # tables only / fills only
+    t1.fill_(float("nan"))
+    _lib.check(lib.sca_theta_prep_zero(theta.data_ptr(), G, C, t1.data_ptr(), l1.data_ptr(), None, 0, None, 0, st), "tpz")
+    za.fill_(3.0)
+    _lib.check(lib.sca_theta_prep_zero(None, 0, 0, None, None, za.data_ptr(), 16 * 10, None, 0, st), "tpz")
+    torch.cuda.synchronize()
+    assert torch.equal(t0, t1) and float(za[:40].abs().max()) == 0.0 and torch.all(za[40:] == 3.0)
+    assert lib.sca_theta_prep_zero(theta.data_ptr(), G, C, t1.data_ptr(), l1.data_ptr(), za.data_ptr() + 4, 16, None, 0, st) == -1
+    assert lib.sca_theta_prep_zero(theta.data_ptr(), G, C, t1.data_ptr(), l1.data_ptr(), za.data_ptr(), 20, None, 0, st) == -1
